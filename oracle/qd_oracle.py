@@ -1,0 +1,706 @@
+"""
+NumPy float64 ORACLE for the QADAPT per-step charge-stability simulation.
+
+THIS FILE IS TEST INFRASTRUCTURE.  It is a CPU restatement of the reference
+algorithm (edwindn/rl-agent-for-qubit-array-tuning), function by function, with
+the reference's quirks kept.  Only `tests/`, `__graft_entry__.smoke()` and the
+`cpu_baseline` leg of `bench.py` may import it, and only as the checker.  The
+product (`rl-agent-for-qubit-array-tuning_amd/`) never imports anything from
+`oracle/`.
+
+Parity status
+-------------
+* The reference's own hot path cannot be imported here (jax / qarray / gymnasium
+  / ray are absent, no network) and the reference holds NO golden vectors for
+  this path.  What does import -- `KalmanUpdater.py` and
+  `GateVoltageComposer.py` -- was used, in this container only, to produce the
+  fixtures under `tests/golden/` (script: `tests/golden/make_golden.py`); the
+  Kalman and sweep-grid parts of this oracle are pinned to those.
+* Everything else (a6-a15, a17, a20-a23) is **parity unpinned** against the
+  reference binary: it is pinned by line-by-line restatement (citations below)
+  plus analytic known-answer tests (tests/test_oracle_known_answers.py).
+* The stochastic parts that live in third-party `qarray==1.6.0`
+  (LatchingModel.add_latching, WhiteNoise/TelegraphNoise) are not restated
+  here: deterministic parity is defined with latching off and noise amplitudes 0.
+
+All `file:line` citations are relative to /root/reference/.
+Precision: float64 throughout (training sets JAX_ENABLE_X64=true,
+src/qadapt/training/training_config.yaml:52), float32 only where the reference
+casts (actions env.py:265-266, normalised obs env.py:509-532, ground truth
+env.py:339-345).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+K_STATES = 32          # qarray_config.yaml:129  latched_model.num_charge_states
+CHUNK = 1000           # qarray_config.yaml:130  latched_model.charge_state_batch_size
+DELTAS = np.array([-1, 0, 1, 2])   # charge_states.py:145
+N_PEAK = 5             # TunnelCoupledChargeSensed.py:77
+
+
+# --------------------------------------------------------------------------
+# a6  Maxwell conversion  (_helper_functions.py:60-126, 129-164)
+# --------------------------------------------------------------------------
+def convert_to_maxwell(cdd_nm, cgd_nm):
+    """_helper_functions.py:129-164.  Returns (cdd, cdd_inv, cgd_negative)."""
+    cdd_nm = np.array(cdd_nm, dtype=np.float64, copy=True)
+    cgd_nm = np.array(cgd_nm, dtype=np.float64, copy=True)
+    cdd_sum = cdd_nm.sum(axis=1)
+    cgd_sum = cgd_nm.sum(axis=1)
+    np.fill_diagonal(cdd_nm, 0)
+    cdd = np.diag(cdd_sum + cgd_sum) - cdd_nm
+    return cdd, np.linalg.inv(cdd), -cgd_nm
+
+
+def maxwell_with_barriers_and_sensor(Cdd, Cgd, Cds, Cgs, Cbd, Cbs):
+    """_helper_functions.py:60-126 (Cbg/Cbb do not enter: barriers are voltage
+    sources).  Charge nodes = dots + 1 sensor; voltage nodes = gates + barriers."""
+    Cdd = np.asarray(Cdd, float); Cgd = np.asarray(Cgd, float)
+    Cds = np.asarray(Cds, float); Cgs = np.asarray(Cgs, float)
+    Cbd = np.asarray(Cbd, float); Cbs = np.asarray(Cbs, float)
+    n_dot = Cdd.shape[0]; n_sensor = Cds.shape[0]
+    n_gate = Cgd.shape[1]; n_barrier = Cbd.shape[1]
+    nodes = n_dot + n_sensor
+    cdd_full = np.zeros((nodes, nodes))
+    cdd_full[:n_dot, :n_dot] = Cdd
+    cdd_full[n_dot:, :n_dot] = Cds
+    cdd_full[:n_dot, n_dot:] = Cds.T
+    cgd_full = np.zeros((nodes, n_gate + n_barrier))
+    cgd_full[:n_dot, :n_gate] = Cgd
+    cgd_full[n_dot:, :n_gate] = Cgs
+    cgd_full[:n_dot, n_gate:] = Cbd
+    cgd_full[n_dot:, n_gate:] = Cbs
+    return convert_to_maxwell(cdd_full, cgd_full)
+
+
+class Device:
+    """The per-episode physical device: what TunnelCoupledChargeSensed holds
+    after __post_init__ (TunnelCoupledChargeSensed.py:94-190) plus the barrier
+    model (barrier_voltage_model.py:21-53)."""
+
+    def __init__(self, Cdd, Cgd, Cds, Cgs, Cbd, Cbg, Cbs, Cbb, tc_base, alpha,
+                 coulomb_peak_width, optimal_tc=1e-3,
+                 optimal_center=(1.0, 0.53)):
+        self.Cdd = np.asarray(Cdd, float); self.Cgd = np.asarray(Cgd, float)
+        self.Cds = np.asarray(Cds, float).reshape(1, -1)
+        self.Cgs = np.asarray(Cgs, float).reshape(1, -1)
+        self.Cbd = np.asarray(Cbd, float); self.Cbg = np.asarray(Cbg, float)
+        self.Cbs = np.asarray(Cbs, float).reshape(1, -1)
+        self.Cbb = np.asarray(Cbb, float)
+        self.n_dot = self.Cdd.shape[0]
+        self.n_gate = self.Cgd.shape[1]            # plungers + sensor gate
+        self.n_barrier = self.Cbd.shape[1]
+        self.tc_base = float(tc_base)
+        self.alpha = np.asarray(alpha, float).reshape(-1)
+        self.gamma = float(coulomb_peak_width)
+        self.optimal_tc = float(optimal_tc)
+        self.cdd_full, self.cdd_inv_full, self.cgd_full = \
+            maxwell_with_barriers_and_sensor(self.Cdd, self.Cgd, self.Cds,
+                                             self.Cgs, self.Cbd, self.Cbs)
+        # qarray_base_class.py:71-73
+        self.n_star = np.array([optimal_center[0]] * self.n_dot + [optimal_center[1]])
+
+
+# --------------------------------------------------------------------------
+# a5  virtual-gate sweep grid
+#     (qarray_base_class.py:95-168, GateVoltageComposer.py:170-211,224-255,277-282)
+# --------------------------------------------------------------------------
+def sweep_voltages(vgm, origin, gate_voltages, sensor_voltage, ch, w_min, w_max, R):
+    """Physical gate voltages (R*R, G) of CSD channel `ch` (dots ch, ch+1),
+    pixel p = y*R + x with x <-> dot ch, y <-> dot ch+1 (row-major flatten)."""
+    gate_voltages = np.asarray(gate_voltages, dtype=np.float64)
+    v1 = gate_voltages[ch]; v2 = gate_voltages[ch + 1]
+    gv = np.concatenate([gate_voltages, [0.0 if sensor_voltage is None else sensor_voltage]])
+    sweep_x = np.linspace(v1 + w_min, v1 + w_max, R)
+    sweep_y = np.linspace(v2 + w_min, v2 + w_max, R)
+    Vd = np.zeros((R, R, gv.shape[0]))
+    Vd[:] = gv
+    Vd[:, :, ch] = sweep_x[np.newaxis, :]
+    Vd[:, :, ch + 1] = sweep_y[:, np.newaxis]
+    vg = np.einsum('ij,...j->...i', vgm, Vd) + origin
+    return vg.reshape(-1, vg.shape[-1])
+
+
+# --------------------------------------------------------------------------
+# a8  continuous ground state  (charge_states.py:36-88)
+# --------------------------------------------------------------------------
+def continuous_ground_state(v_ext, cdd_inv, cgd, n_dot):
+    """(P,V) -> (P,N).  Analytic cgd[:N]@v where all components >= 0, else 50
+    steps of projected gradient descent (lr 0.1); final clip at 0."""
+    A = cdd_inv[:n_dot, :n_dot]
+    lin = v_ext @ cgd[:n_dot, :].T                      # (P,N)
+    n_cont = lin.copy()
+    bad = ~np.all(n_cont >= 0, axis=-1)
+    if np.any(bad):
+        target = lin[bad]
+        n = np.clip(target, 0, None)
+        for _ in range(50):
+            grad = n @ A.T - target @ A.T
+            n = np.clip(n - 0.1 * grad, 0, None)
+        n_cont[bad] = n
+    return np.clip(n_cont, 0, None)
+
+
+# --------------------------------------------------------------------------
+# a9  top-K candidate charge states
+#     (charge_states.py:135-222 via build_charge_states :226-250)
+# --------------------------------------------------------------------------
+def _delta_table(n_dot):
+    """All 4^N delta vectors, base-4 digits with the MOST significant digit on
+    dot 0 (charge_states.py:176-179)."""
+    total = 4 ** n_dot
+    idx = np.arange(total)
+    digits = np.zeros((total, n_dot), dtype=np.int64)
+    t = idx.copy()
+    for i in range(n_dot):
+        digits[:, n_dot - 1 - i] = t % 4
+        t //= 4
+    return DELTAS[digits]                                 # (4^N, N)
+
+
+def candidate_states_literal(v_ext, cdd_inv, cgd, n_dot, k=K_STATES, chunk=CHUNK):
+    """Literal chunked scan (charge_states.py:161-220): per chunk a stable
+    argsort[:k], merged into the running best by a stable argsort of
+    concat([best, chunk_best]).  Running best starts as k x (+inf, zero state),
+    which is where the duplicate |0...0> padding comes from.
+    Returns (states int32 (P,k,N), n_continuous (P,N))."""
+    v_ext = np.atleast_2d(np.asarray(v_ext, float))
+    P = v_ext.shape[0]
+    A = cdd_inv[:n_dot, :n_dot]
+    n_cont = continuous_ground_state(v_ext, cdd_inv, cgd, n_dot)
+    floor_values = np.floor(n_cont)
+    v_dash = v_ext @ cgd[:n_dot, :].T
+    total = 4 ** n_dot
+    n_chunks = (total + chunk - 1) // chunk
+    table = _delta_table(n_dot).astype(np.float64)
+    out = np.zeros((P, k, n_dot), dtype=np.int32)
+    for p in range(P):
+        best_e = np.full(k, np.inf)
+        best_s = np.zeros((k, n_dot))
+        for c in range(n_chunks):
+            base = np.arange(chunk) + c * chunk
+            within = base < total
+            safe = base % total
+            cfg = table[safe] + floor_values[p]
+            valid = np.all(cfg >= 0, axis=-1) & within
+            d = cfg - v_dash[p]
+            e = np.einsum('...i,ij,...j', d, A, d)
+            e = np.where(valid, e, np.inf)
+            ci = np.argsort(e, kind='stable')[:k]
+            comb_e = np.concatenate([best_e, e[ci]])
+            comb_s = np.concatenate([best_s, cfg[ci]], axis=0)
+            fi = np.argsort(comb_e, kind='stable')[:k]
+            best_e = comb_e[fi]; best_s = comb_s[fi]
+        out[p] = best_s.astype(np.int32)
+    return out, n_cont
+
+
+def candidate_states(v_ext, cdd_inv, cgd, n_dot, k=K_STATES, block=128):
+    """Same result as `candidate_states_literal` (tests prove it), computed as
+    one global stable sort per pixel: the merge of stable per-chunk top-k lists
+    in chunk order is the global stable top-k by (energy, index); the padding is
+    the zero state whenever fewer than k candidates are valid."""
+    v_ext = np.atleast_2d(np.asarray(v_ext, float))
+    P = v_ext.shape[0]
+    A = cdd_inv[:n_dot, :n_dot]
+    n_cont = continuous_ground_state(v_ext, cdd_inv, cgd, n_dot)
+    floor_values = np.floor(n_cont)
+    v_dash = v_ext @ cgd[:n_dot, :].T
+    table = _delta_table(n_dot).astype(np.float64)
+    out = np.zeros((P, k, n_dot), dtype=np.int32)
+    for s in range(0, P, block):
+        e_ = slice(s, min(P, s + block))
+        cfg = table[None, :, :] + floor_values[e_, None, :]          # (b,T,N)
+        d = cfg - v_dash[e_, None, :]
+        e = np.einsum('...i,ij,...j', d, A, d)
+        e = np.where(np.all(cfg >= 0, axis=-1), e, np.inf)
+        order = np.argsort(e, axis=-1, kind='stable')[:, :k]
+        if order.shape[1] < k:                                       # 4^N < k (N=2)
+            pad = np.zeros((order.shape[0], k - order.shape[1]), dtype=order.dtype)
+            e_sel = np.concatenate([np.take_along_axis(e, order, -1),
+                                    np.full(pad.shape, np.inf)], axis=-1)
+            order = np.concatenate([order, pad], axis=-1)
+        else:
+            e_sel = np.take_along_axis(e, order, -1)
+        st = np.take_along_axis(cfg, order[:, :, None], axis=1)
+        st = np.where(np.isinf(e_sel)[:, :, None], 0.0, st)
+        out[e_] = st.astype(np.int32)
+    return out, n_cont
+
+
+# --------------------------------------------------------------------------
+# a10  barrier model  (barrier_voltage_model.py:55-94, 96-151)
+# --------------------------------------------------------------------------
+def effective_barrier_potential(vg, vb, Cbg, Cbb):
+    V_direct = vb + np.einsum('bg,...g->...b', Cbg, vg)
+    Cbb_off = Cbb - np.diag(np.diag(Cbb))
+    # QUIRK kept: 'bb,...b->...b' takes the DIAGONAL of a zero-diagonal matrix,
+    # so the cross-barrier term is identically zero (barrier_voltage_model.py:142).
+    cross = np.einsum('bb,...b->...b', Cbb_off, V_direct)
+    return V_direct + cross
+
+
+def tunnel_couplings(vb_eff, tc_base, alpha):
+    """tc_d = tc_base * exp(-alpha_d * vb_eff_d)  (no abs, :83)."""
+    return tc_base * np.exp(-alpha * vb_eff)
+
+
+# --------------------------------------------------------------------------
+# a11  free energy of the kept states  (hamiltonian_build.py:12-45)
+# --------------------------------------------------------------------------
+def free_energy_states(v_ext, cdd_inv, cgd, states, n_dot):
+    gate_effect = v_ext @ cgd[:n_dot, :].T                 # (P,N)
+    A = cdd_inv[:n_dot, :n_dot]
+    inner = states - gate_effect[:, None, :]               # (P,M,N)
+    return np.einsum('...ni,ij,...nj->...n', inner, A, inner)
+
+
+# --------------------------------------------------------------------------
+# a12  tunnelling Hamiltonian, "fermionic_negative"  (hamiltonian_build.py:75-137)
+# --------------------------------------------------------------------------
+def tunnel_hamiltonian(tc, states):
+    """tc: (P, N-1) couplings of adjacent pairs; states: (P,M,N) ints -> (P,M,M)."""
+    st = states.astype(np.float64)
+    P, M, N = st.shape
+    si = st[:, :, None, :]; sj = st[:, None, :, :]
+    diff = sj - si                                          # (P,M,M,N)
+    H = np.zeros((P, M, M))
+    for d in range(N - 1):
+        exp_diff = np.zeros(N); exp_diff[d] = -1; exp_diff[d + 1] = 1
+        fwd = np.all(diff == exp_diff, axis=-1)
+        bwd = np.all(diff == -exp_diff, axis=-1)
+        n_from = si[..., d]; n_to = si[..., d + 1]          # taken from state i
+        t = tc[:, d][:, None, None]
+        H = H + fwd * (-t * np.sqrt(n_from * (n_to + 1)))
+        H = H + bwd * (-t * np.sqrt(n_to * (n_from + 1)))
+    return H
+
+
+# --------------------------------------------------------------------------
+# a7 + a13  ground state expectation occupations  (ground_state.py:24-166)
+# --------------------------------------------------------------------------
+def ground_state_open(dev: Device, vg, vb, return_states=False, fast_candidates=True):
+    """vg (P,G) physical gate voltages, vb (P,n_b).  Returns n (P,N) float64
+    (latching model = identity)."""
+    vg = np.asarray(vg, float).reshape(-1, dev.n_gate)
+    vb = np.asarray(vb, float).reshape(-1, dev.n_barrier)
+    v_ext = np.concatenate([vg, vb], axis=-1)
+    N = dev.n_dot
+    fn = candidate_states if fast_candidates else candidate_states_literal
+    states, _ = fn(v_ext, dev.cdd_inv_full, dev.cgd_full, N)
+    vb_eff = effective_barrier_potential(vg, vb, dev.Cbg, dev.Cbb)
+    tc = tunnel_couplings(vb_eff, dev.tc_base, dev.alpha)
+    F = free_energy_states(v_ext, dev.cdd_inv_full, dev.cgd_full, states, N)
+    M = states.shape[1]
+    H = F[:, :, None] * np.eye(M) + tunnel_hamiltonian(tc, states)
+    _, vecs = np.linalg.eigh(H)
+    g = vecs[..., :, 0]
+    probs = np.abs(g) ** 2
+    n = np.einsum('...m,...md->...d', probs, states.astype(np.float64))
+    if return_states:
+        return n, states, F, tc
+    return n
+
+
+# --------------------------------------------------------------------------
+# a15  charge-sensor response  (TunnelCoupledChargeSensed.py:320-380,
+#      lorentzian _helper_functions.py:167-177); noise model = none
+# --------------------------------------------------------------------------
+def charge_sensor_open(dev: Device, vg, vb, n_open=None):
+    vg = np.asarray(vg, float).reshape(-1, dev.n_gate)
+    vb = np.asarray(vb, float).reshape(-1, dev.n_barrier)
+    if n_open is None:
+        n_open = ground_state_open(dev, vg, vb)
+    v_ext = np.concatenate([vg, vb], axis=-1)
+    N = dev.n_dot
+    N_cont = np.einsum('ij,...j', dev.cgd_full, v_ext)
+    N_sensor = np.round(N_cont[..., N:N + 1])
+    F = np.zeros((2 * N_PEAK + 1, *N_sensor.shape))
+    v_dash = np.einsum('ij,...j', dev.cgd_full, v_ext)
+    for i, k in enumerate(range(-N_PEAK, N_PEAK + 1)):
+        pert = N_sensor.copy()
+        pert[..., 0] = pert[..., 0] + k
+        N_full = np.concatenate([n_open, pert], axis=-1)
+        d = N_full - v_dash
+        F[i, ..., 0] = np.einsum('...i,ij,...j', d, dev.cdd_inv_full, d)
+    with np.errstate(divide='ignore', invalid='ignore'):
+        x = np.diff(F, axis=0)
+        signal = np.reciprocal((x / dev.gamma) ** 2 + 1).sum(axis=0)
+    return signal, n_open
+
+
+# --------------------------------------------------------------------------
+# a4  raw observation: C channel images  (qarray_base_class.py:171-229)
+# --------------------------------------------------------------------------
+def get_obs_images(dev: Device, vgm, origin, gate_voltages, barrier_voltages,
+                   sensor_voltage, window, R, return_occupations=False):
+    """(R,R,C) float64 unnormalised CSD stack (radial noise off)."""
+    N = dev.n_dot
+    imgs, occs = [], []
+    for ch in range(N - 1):
+        vg = sweep_voltages(vgm, origin, gate_voltages, sensor_voltage, ch,
+                            -window, window, R)
+        vb = np.broadcast_to(np.asarray(barrier_voltages, float), (vg.shape[0], N - 1))
+        z, n_open = charge_sensor_open(dev, vg, vb)
+        imgs.append(z.reshape(R, R)); occs.append(n_open.reshape(R, R, N))
+    img = np.stack(imgs, axis=-1)
+    if return_occupations:
+        return img, np.stack(occs, axis=0)
+    return img
+
+
+# --------------------------------------------------------------------------
+# a17  normalisation  (env.py:471-534)
+# --------------------------------------------------------------------------
+def normalise_image(image):
+    p_low = np.percentile(image, 0.5)
+    p_high = np.percentile(image, 99.5)
+    if p_high > p_low:
+        out = (image - p_low) / (p_high - p_low)
+    else:
+        out = np.zeros_like(image)
+    return np.clip(out, 0.0, 1.0).astype(np.float32)
+
+
+def normalise_voltages(v, low, high):
+    v = np.asarray(v).astype(np.float32)
+    v = (v - low) / (high - low)
+    v = v * 2 - 1
+    return v.astype(np.float32)
+
+
+# --------------------------------------------------------------------------
+# a19  Kalman capacitance updater  (KalmanUpdater.py:28-227) -- pinned to
+#      tests/golden/kalman_*.npz generated from the reference class itself
+# --------------------------------------------------------------------------
+class KalmanOracle:
+    def __init__(self, n_dots, prior_mean=0.3, prior_variance=0.5,
+                 variance_threshold=0.05, process_noise=0.0, include_nnn=True,
+                 mean_bounds=(-1.0, 1.0), log_var_bounds=(-6.0, 2.0),
+                 prior_mean_nnn=0.15):
+        self.n = n_dots
+        self.thr = variance_threshold; self.q = process_noise
+        self.include_nnn = include_nnn
+        self.mb = mean_bounds; self.lb = log_var_bounds
+        self.means = np.zeros((n_dots, n_dots)); self.vars = np.zeros((n_dots, n_dots))
+        for i in range(n_dots - 1):
+            self.means[i, i + 1] = self.means[i + 1, i] = prior_mean
+            self.vars[i, i + 1] = self.vars[i + 1, i] = prior_variance
+        if include_nnn:
+            pm = prior_mean if prior_mean_nnn is None else prior_mean_nnn
+            for i in range(n_dots - 2):
+                self.means[i, i + 2] = self.means[i + 2, i] = pm
+                self.vars[i, i + 2] = self.vars[i + 2, i] = prior_variance
+
+    def _update(self, i, j, delta, R):
+        r, c = min(i, j), max(i, j)
+        if R > self.thr:
+            return False
+        P = self.vars[r, c] + self.q
+        x = self.means[r, c]
+        K = P / (P + R)
+        nm = float(np.clip(x + K * delta, self.mb[0], self.mb[1]))
+        nv = (1 - K) * P
+        self.means[r, c] = self.means[c, r] = nm
+        self.vars[r, c] = self.vars[c, r] = nv
+        return True
+
+    def update_from_scan(self, left, outs):
+        i = left
+        var = lambda lv: float(np.exp(np.clip(lv, self.lb[0], self.lb[1])))
+        self._update(i, i + 1, outs[0][0], var(outs[0][1]))
+        if i + 2 < self.n:
+            self._update(i, i + 2, outs[1][0], var(outs[1][1]))
+        if i - 1 >= 0:
+            self._update(i + 1, i - 1, outs[2][0], var(outs[2][1]))
+
+    def update_from_cnn(self, values, log_vars):
+        """env.py:608-618: per channel i, the three CNN outputs NEGATED."""
+        for i in range(self.n - 1):
+            self.update_from_scan(i, [(-float(values[i, k]), float(log_vars[i, k]))
+                                      for k in range(3)])
+
+    def full_matrix(self):
+        m = self.means.copy()
+        np.fill_diagonal(m, 1.0)
+        return m
+
+
+# --------------------------------------------------------------------------
+# a20  VGM from the capacitance estimate  (qarray_base_class.py:904-942)
+# --------------------------------------------------------------------------
+def vgm_from_estimate(dev: Device, cgd_estimate):
+    N = dev.n_dot; nb = dev.n_barrier
+    est = np.hstack([cgd_estimate, np.zeros((N, 1)), np.zeros((N, nb))])
+    est = np.vstack([est, np.zeros((1, N + nb + 1))])
+    est[-1, N] = 1.0
+    est = -est
+    gates_only = est[:, :dev.n_gate]
+    vgm = -np.linalg.pinv(dev.cdd_inv_full @ gates_only)
+    return -vgm                                   # charge_carrier == 'electrons' (:938-939)
+
+
+def identity_vgm(n_dot):
+    """qarray_base_class.py:868-876 with the electrons sign."""
+    return -np.eye(n_dot + 1)
+
+
+# --------------------------------------------------------------------------
+# a21  ground truth  (qarray_base_class.py:1233-1286,
+#      TunnelCoupledChargeSensed.py:445-471)
+# --------------------------------------------------------------------------
+def optimal_vg(dev: Device, rcond=1e-3):
+    cgd_gates = dev.cgd_full[:, :dev.n_gate]
+    Rm = np.linalg.cholesky(dev.cdd_inv_full).T
+    M = np.linalg.pinv(Rm @ cgd_gates, rcond=rcond) @ Rm
+    return np.einsum('ij,...j', M, dev.n_star)
+
+
+def ground_truth(dev: Device, vgm, origin):
+    """-> (plunger gt float32 (N,), barrier gt float32 (N-1,), sensor gt float)."""
+    vopt = optimal_vg(dev)
+    tc_ratio = dev.optimal_tc / dev.tc_base
+    vb_base = np.array([-np.log(tc_ratio) / a for a in dev.alpha])
+    vb_opt = vb_base - dev.Cbg @ vopt
+    virt = np.linalg.inv(vgm) @ (vopt - origin)
+    return (virt[:-1].astype(np.float32), vb_opt.astype(np.float32), float(virt[-1]))
+
+
+# --------------------------------------------------------------------------
+# a2 / a3  action rescale and reward  (env.py:260-285, 350-462, 861-876)
+# --------------------------------------------------------------------------
+def rescale(action, lo, hi):
+    a = np.clip(np.array(action).flatten().astype(np.float32), -1, 1)
+    a = (a + 1) / 2
+    return a * (hi - lo) + lo
+
+
+def reward(dev: Device, gate_gt, barrier_gt, gate_v, barrier_v,
+           gate_ramp_start=40.0, gate_quadratic_start=1.0, barrier_ramp_start=6.0):
+    """Non-sparse reward with gate_curve_type 'constant' (env_config.yaml)."""
+    N = dev.n_dot
+    gd = np.abs(gate_gt - gate_v) * np.abs([dev.cgd_full[i, i] for i in range(N)])
+    bd = np.abs(barrier_gt - barrier_v) * dev.alpha
+    gr = np.zeros_like(gd)
+    for i, d in enumerate(gd):
+        if d >= gate_ramp_start:
+            gr[i] = 0.0
+        elif d > gate_quadratic_start:
+            gr[i] = 0.5 * (gate_ramp_start - d) / (gate_ramp_start - gate_quadratic_start)
+        else:
+            gr[i] = 0.5 + 0.5 * 1
+    br = np.zeros_like(bd)
+    for i, d in enumerate(bd):
+        br[i] = 0.0 if d >= barrier_ramp_start else (barrier_ramp_start - d) / barrier_ramp_start
+    return np.clip(gr, 0, 1), np.clip(br, 0, 1)
+
+
+# --------------------------------------------------------------------------
+# a22  per-agent observations  (multi_agent_wrapper.py:147-178, 311-383)
+# --------------------------------------------------------------------------
+def agent_images(image, n_dot):
+    """image (R,R,C) f32 -> dict agent_id -> (R,R,2|1) f32."""
+    out = {}
+    for i in range(n_dot):
+        if i == 0:
+            a = np.stack([image[:, :, 0], image[:, :, 0]], axis=2)
+        elif i == n_dot - 1:
+            t = image[:, :, n_dot - 2].T
+            a = np.stack([t, t], axis=2)
+        else:
+            a = np.stack([image[:, :, i - 1], image[:, :, i].T], axis=2)
+        out[f"plunger_{i}"] = a.astype(np.float32)
+    for j in range(n_dot - 1):
+        out[f"barrier_{j}"] = image[:, :, j:j + 1].astype(np.float32)
+    return out
+
+
+# --------------------------------------------------------------------------
+# a23  reset-time device sampling  (qarray_base_class.py:254-390, 495-555,
+#      611-700) in the reference's draw order, from ONE numpy Generator.
+#      The reference itself uses unseeded generators, so only the ranges and
+#      the construction rules are contractual; the draw order below is this
+#      repo's definition and the product's sampler must reproduce it exactly.
+# --------------------------------------------------------------------------
+DEFAULT_PRIORS = {
+    "Cdd": {1: (0.0, 0.2), 2: (0.0, 0.1), 3: (0.0, 0.0)},
+    "Cgd_primary": (0.95, 1.0),
+    "Cgd_cross": {1: (0.3, 0.7), 2: (0.01, 0.3), 3: (0.0, 0.01)},
+    "Cds": (0.035, 0.050),
+    "Cgs_plunger": (0.0, 0.0001), "Cgs_sensor": (0.95, 1.0),
+    "white_noise_amplitude": (0.0, 0.0001),
+    "telegraph": {"p01": (0.0, 0.01), "p10_factor": (0, 100), "amplitude": (0.0, 0.012)},
+    "latching": {"p_leads": (0.2, 1.0), "p_inter": (0.2, 1.0)},
+    "T": (50, 200), "coulomb_peak_width": (0.0, 0.4), "tc": (0.1, 0.2),
+    "Cbd": {1: (0.04, 0.08), 2: (0.01, 0.03), 3: (0.005, 0.015)},
+    "Cbg": {1: (0.08, 0.15), 2: (0.03, 0.18), 3: (0.01, 0.03)},
+    "Cbs": (0.0003, 0.001),
+    "Cbb": {1: (0.03, 0.08), 2: (0.01, 0.03), 3: (0.005, 0.015)}, "Cbb_diag": 1.0,
+    "tc_base": (0.5, 3.0), "alpha": (0.8, 2.0),
+    "vcap_alpha": (0.05, 0.10), "vcap_beta": (0.05, 0.10),
+    "vpw_alpha": (0.0001, 0.0008),
+    "radial": {"enabled": True, "lower": (20, 30), "ramp_range": (5, 10),
+               "total_noise_range": (30, 40), "max_amplitude": 0.05},
+    "window_delta": (1.5, 2.0), "offset": (0.0, 0.0),
+    "plunger_range": (80, 100), "barrier_range": (20, 30),
+}
+
+
+def _band(tbl, dist):
+    return tbl[1] if dist == 1 else tbl[2] if dist == 2 else tbl[3]
+
+
+def sample_episode(rng: np.random.Generator, N, pri=DEFAULT_PRIORS):
+    """One episode's random draws, literal scalar `rng.uniform` calls."""
+    u = lambda r: rng.uniform(r[0], r[1])
+    nb = N - 1
+    out = {"window_delta": u(pri["window_delta"])}              # env.py:160-164
+    # Cdd (:254-268)
+    Cdd = np.zeros((N, N))
+    for i in range(N):
+        for j in range(i, N):
+            v = 0.0 if i == j else u(_band(pri["Cdd"], j - i))
+            Cdd[i, j] = Cdd[j, i] = v
+    # Cgd (:270-298)
+    Cgd = np.zeros((N, N + 1))
+    for i in range(N):
+        for j in range(N):
+            d = abs(i - j)
+            Cgd[i, j] = u(pri["Cgd_primary"]) if d == 0 else u(_band(pri["Cgd_cross"], d))
+    for i in range(N):
+        for j in range(i + 1, N):
+            avg = (Cgd[i, j] + Cgd[j, i]) / 2
+            Cgd[i, j] = Cgd[j, i] = avg
+    # Cds, Cgs (:376-390)
+    Cds = np.array([[u(pri["Cds"]) for _ in range(N)]])
+    cgs = [u(pri["Cgs_plunger"]) for _ in range(N)]
+    cgs.append(u(pri["Cgs_sensor"]))
+    Cgs = np.array([cgs])
+    # Cbd (:300-319)
+    Cbd = np.zeros((N, nb))
+    for i in range(N):
+        for j in range(nb):
+            d = max(1, int(abs(i - (j + 0.5))))
+            Cbd[i, j] = u(_band(pri["Cbd"], d))
+    # Cbg (:321-345)
+    Cbg = np.zeros((nb, N + 1))
+    for i in range(nb):
+        for j in range(N + 1):
+            d = max(1, int(abs((i + 0.5) - j))) if j < N else 2
+            Cbg[i, j] = u(_band(pri["Cbg"], d))
+    # Cbs (:347-358)
+    Cbs = np.array([[u(pri["Cbs"]) for _ in range(nb)]])
+    # Cbb (:360-374)
+    Cbb = np.zeros((nb, nb))
+    for i in range(nb):
+        for j in range(i, nb):
+            v = pri["Cbb_diag"] if i == j else u(_band(pri["Cbb"], j - i))
+            Cbb[i, j] = Cbb[j, i] = v
+    # noise (:392-442)
+    out["white_noise_amplitude"] = u(pri["white_noise_amplitude"])
+    p01 = u(pri["telegraph"]["p01"]); f = u(pri["telegraph"]["p10_factor"])
+    out["telegraph"] = {"p01": p01, "p10": f * p01, "amplitude": u(pri["telegraph"]["amplitude"])}
+    if pri["radial"]["enabled"]:
+        zr = u(pri["radial"]["lower"]); dl = u(pri["radial"]["ramp_range"])
+        out["radial"] = {"zero_radius": zr, "ramp_distance": zr + dl,
+                         "full_noise_distance": u(pri["radial"]["total_noise_range"])}
+    # latching (:495-519)
+    p_inter = np.zeros((N, N))
+    for i in range(N):
+        for j in range(i, N):
+            v = 0.0 if i == j else u(pri["latching"]["p_inter"])
+            p_inter[i, j] = p_inter[j, i] = v
+    out["latching"] = {"p_inter": p_inter,
+                       "p_leads": np.array([u(pri["latching"]["p_leads"]) for _ in range(N)])}
+    # barrier model (:521-534)
+    tc_base = u(pri["tc_base"])
+    alpha = np.array([u(pri["alpha"]) for _ in range(nb)])
+    # unused-by-default draws, kept so the stream stays aligned (:536-555, :685-687)
+    out["vcap"] = (u(pri["vcap_alpha"]), u(pri["vcap_beta"]))
+    out["vpw_alpha"] = u(pri["vpw_alpha"])
+    out["T"] = u(pri["T"])
+    gamma = u(pri["coulomb_peak_width"])
+    out["tc"] = u(pri["tc"])
+    out.update(Cdd=Cdd, Cgd=Cgd, Cds=Cds, Cgs=Cgs, Cbd=Cbd, Cbg=Cbg, Cbs=Cbs, Cbb=Cbb,
+               tc_base=tc_base, alpha=alpha, coulomb_peak_width=gamma)
+    # env.py:184-189 offset; :808-858 ranges and start (needs ground truth, so the
+    # raw uniforms are drawn here and applied by OracleEnv.reset)
+    out["offset"] = np.array([u(pri["offset"]) for _ in range(N)])
+    out["u_plunger_range"] = rng.uniform(*pri["plunger_range"])
+    out["u_plunger_center"] = rng.uniform(0.0, 1.0, size=N)
+    out["u_barrier_range"] = rng.uniform(*pri["barrier_range"])
+    out["u_barrier_center"] = rng.uniform(0.0, 1.0, size=nb)
+    out["u_start_plunger"] = rng.uniform(0.0, 1.0, size=N)
+    out["u_start_barrier"] = rng.uniform(0.0, 1.0, size=nb)
+    return out
+
+
+def device_from_sample(s) -> Device:
+    return Device(s["Cdd"], s["Cgd"], s["Cds"], s["Cgs"], s["Cbd"], s["Cbg"], s["Cbs"],
+                  s["Cbb"], s["tc_base"], s["alpha"], s["coulomb_peak_width"])
+
+
+# --------------------------------------------------------------------------
+# a1-a4, a17-a23 glued: one environment  (env.py:135-315)
+# --------------------------------------------------------------------------
+class OracleEnv:
+    """Single-env restatement of QuantumDeviceEnv.reset/step with the CNN
+    replaced by caller-supplied (values, log_vars) of shape (C,3) (row f1 of
+    SURVEY §8 is out of scope; env.py:568-581 is an input provider here)."""
+
+    def __init__(self, n_dot, resolution, max_steps=50):
+        self.N = n_dot; self.R = resolution; self.max_steps = max_steps
+        # QUIRK kept: the Kalman filter is built once in __init__ (env.py:130,
+        # 779-787) and is NOT reset by reset(); it survives episodes.
+        self.kalman = KalmanOracle(n_dot)
+
+    def reset(self, sample, cnn_values, cnn_log_vars):
+        s = sample; N = self.N
+        self.step_count = 0
+        self.window = s["window_delta"]
+        self.dev = device_from_sample(s)
+        self.vgm = identity_vgm(N)                                   # env.py:179
+        self.origin = np.concatenate([s["offset"], [0.0]])           # env.py:193
+        pgt, bgt, sgt = ground_truth(self.dev, self.vgm, self.origin)
+        # env.py:808-839 (np.random.uniform(low, high) == low + (high-low)*u)
+        pr = s["u_plunger_range"]
+        lo = pgt - 0.5 * (pr - 2); hi = pgt + 0.5 * (pr - 2)
+        pc = lo + (hi - lo) * s["u_plunger_center"]
+        self.plunger_max = pc + 0.5 * pr; self.plunger_min = pc - 0.5 * pr
+        br = s["u_barrier_range"]
+        lo = bgt - 0.5 * (br - 1); hi = bgt + 0.5 * (br - 1)
+        bc = lo + (hi - lo) * s["u_barrier_center"]
+        self.barrier_max = bc + 0.5 * br; self.barrier_min = bc - 0.5 * br
+        # env.py:842-858
+        self.gate_v = self.plunger_min + (self.plunger_max - self.plunger_min) * s["u_start_plunger"]
+        self.barrier_v = self.barrier_min + (self.barrier_max - self.barrier_min) * s["u_start_barrier"]
+        self.gate_gt, self.barrier_gt, self.sensor_gt = ground_truth(self.dev, self.vgm, self.origin)
+        obs = self._observe()
+        self._kalman_and_vgm(cnn_values, cnn_log_vars)
+        return obs
+
+    def _observe(self):
+        raw = get_obs_images(self.dev, self.vgm, self.origin, self.gate_v, self.barrier_v,
+                             self.sensor_gt, self.window, self.R)
+        self.raw_image = raw
+        return {"image": normalise_image(raw),
+                "obs_gate_voltages": normalise_voltages(self.gate_v, self.plunger_min, self.plunger_max),
+                "obs_barrier_voltages": normalise_voltages(self.barrier_v, self.barrier_min, self.barrier_max)}
+
+    def _kalman_and_vgm(self, values, log_vars):
+        self.kalman.update_from_cnn(np.asarray(values), np.asarray(log_vars))
+        self.vgm = vgm_from_estimate(self.dev, self.kalman.full_matrix())
+
+    def step(self, gate_action, barrier_action, cnn_values, cnn_log_vars):
+        self.step_count += 1
+        self.gate_v = rescale(gate_action, self.plunger_min, self.plunger_max)
+        self.barrier_v = rescale(barrier_action, self.barrier_min, self.barrier_max)
+        # QUIRK kept: reward is against the ground truth of the PREVIOUS step
+        # (env.py:279 runs before :298).
+        rew = reward(self.dev, self.gate_gt, self.barrier_gt, self.gate_v, self.barrier_v)
+        truncated = self.step_count >= self.max_steps
+        obs = self._observe()
+        self._kalman_and_vgm(cnn_values, cnn_log_vars)
+        self.gate_gt, self.barrier_gt, self.sensor_gt = ground_truth(self.dev, self.vgm, self.origin)
+        return obs, rew, False, truncated
