@@ -664,12 +664,15 @@ class OracleEnv:
         self.origin = np.concatenate([s["offset"], [0.0]])           # env.py:193
         pgt, bgt, sgt = ground_truth(self.dev, self.vgm, self.origin)
         # env.py:808-839 (np.random.uniform(low, high) == low + (high-low)*u)
-        pr = s["u_plunger_range"]
-        lo = pgt - 0.5 * (pr - 2); hi = pgt + 0.5 * (pr - 2)
+        # low/high are formed in float32 (float32 ground truth, Python-float half width,
+        # env.py:819-822) and widened to double inside np.random.uniform.
+        pr = float(s["u_plunger_range"])
+        lo = (pgt - 0.5 * (pr - 2)).astype(np.float64); hi = (pgt + 0.5 * (pr - 2)).astype(np.float64)
+        assert (pgt - 0.5 * (pr - 2)).dtype == np.float32
         pc = lo + (hi - lo) * s["u_plunger_center"]
         self.plunger_max = pc + 0.5 * pr; self.plunger_min = pc - 0.5 * pr
-        br = s["u_barrier_range"]
-        lo = bgt - 0.5 * (br - 1); hi = bgt + 0.5 * (br - 1)
+        br = float(s["u_barrier_range"])
+        lo = (bgt - 0.5 * (br - 1)).astype(np.float64); hi = (bgt + 0.5 * (br - 1)).astype(np.float64)
         bc = lo + (hi - lo) * s["u_barrier_center"]
         self.barrier_max = bc + 0.5 * br; self.barrier_min = bc - 0.5 * br
         # env.py:842-858

@@ -1,0 +1,287 @@
+// qd_pixel.h -- the pixel-per-lane part of the hot path as __host__ __device__
+// code: sweep-voltage synthesis (a5), continuous ground state (a8), EXACT
+// k-best candidate search (a9), barrier couplings (a10), sensor stage (a15).
+// The same source is compiled into the HIP kernels and into the CPU-only test
+// harness (qd_hosttest.cpp) so its integer results can be checked against the
+// oracle without a GPU.
+//
+// Reference rows (file:line under /root/reference):
+//   a5  qarray_base_class.py:95-168, GateVoltageComposer.py:170-211
+//   a8  charge_states.py:36-88        a9  charge_states.py:135-222
+//   a10 barrier_voltage_model.py:55-151   a15 TunnelCoupledChargeSensed.py:332-380
+//
+// CANONICAL ARITHMETIC (must match oracle/qd_oracle.c bit for bit, because the
+// results feed integer decisions: floor(), candidate order):
+//   dot(a,b,n)  : acc = 0; for j<n: acc = fma(a[j], b[j], acc)
+//   energy(A,d) : t_i = dot(A[i,:], d); E = 0; for i: E = fma(d[i], t_i, E)
+//   linspace    : start + (double)i*step, step=(stop-start)/(R-1), last point = stop
+// Compile with -ffp-contract=off: only the explicit fma() calls fuse.
+#pragma once
+#include <math.h>
+#include "qd_common.h"
+
+QD_HD double qd_dot(const double* a, const double* b, int n) {
+    double acc = 0.0;
+    for (int j = 0; j < n; ++j) acc = fma(a[j], b[j], acc);
+    return acc;
+}
+
+template <int N>
+QD_HD double qd_dotN(const double* a, const double* b) {
+    double acc = 0.0;
+#pragma unroll
+    for (int j = 0; j < N; ++j) acc = fma(a[j], b[j], acc);
+    return acc;
+}
+
+QD_HD double qd_linspace(double start, double stop, int R, int i) {
+    if (R == 1) return start;
+    if (i == R - 1) return stop;
+    double step = (stop - start) / (double)(R - 1);
+    return start + (double)i * step;
+}
+
+// ---------------------------------------------------------------------------
+// a5 + a8 + a10 front end of one pixel.
+//   par: env parameter block, st: env state block (layout qd_layout(N)).
+// Outputs: v_ext[V] = [physical gate voltages (G), barrier voltages (nb)],
+//          vpp[G] = cgd_full @ v_ext (vpp[0..N) is v'), ncont[N], tc[nb].
+// ---------------------------------------------------------------------------
+template <int N>
+QD_HD void qd_pixel_front(const double* par, const double* st, int ch, int R, int x, int y,
+                          double* v_ext, double* vpp, double* ncont, double* tc) {
+    constexpr int G = N + 1, NB = N - 1, V = 2 * N;
+    const QdLayout L = qd_layout(N);
+    const double* vgm = st + L.s_vgm;
+    const double* gate_v = st + L.s_gate_v;
+    const double* barrier_v = st + L.s_barrier_v;
+    const double sensor_v = st[L.s_sensor_gt];
+    const double window = par[L.scal + 2];
+    double Vd[G];
+#pragma unroll
+    for (int i = 0; i < N; ++i) Vd[i] = gate_v[i];
+    Vd[N] = sensor_v;
+    const double v1 = gate_v[ch], v2 = gate_v[ch + 1];
+    const double sx = qd_linspace(v1 + (-window), v1 + window, R, x);
+    const double sy = qd_linspace(v2 + (-window), v2 + window, R, y);
+#pragma unroll
+    for (int i = 0; i < N; ++i) {            // static indices only (keeps Vd in registers)
+        if (i == ch) Vd[i] = sx;
+        if (i == ch + 1) Vd[i] = sy;
+    }
+#pragma unroll
+    for (int i = 0; i < G; ++i) v_ext[i] = qd_dotN<G>(vgm + i * G, Vd) + par[L.origin + i];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) v_ext[G + b] = barrier_v[b];
+#pragma unroll
+    for (int i = 0; i < G; ++i) vpp[i] = qd_dotN<V>(par + L.cgd + i * V, v_ext);
+    // a8 continuous ground state
+    bool all_pos = true;
+#pragma unroll
+    for (int i = 0; i < N; ++i) { ncont[i] = vpp[i]; if (!(vpp[i] >= 0.0)) all_pos = false; }
+    if (!all_pos) {
+        const double* A = par + L.cdd_inv;
+        double n[N], g2[N], nn[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) n[i] = vpp[i] > 0.0 ? vpp[i] : 0.0;
+#pragma unroll
+        for (int i = 0; i < N; ++i) g2[i] = qd_dotN<N>(A + i * G, vpp);
+        for (int it = 0; it < 50; ++it) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                double g1 = qd_dotN<N>(A + i * G, n);
+                double grad = g1 - g2[i];
+                double v = n[i] - 0.1 * grad;
+                nn[i] = v > 0.0 ? v : 0.0;
+            }
+#pragma unroll
+            for (int i = 0; i < N; ++i) n[i] = nn[i];
+        }
+#pragma unroll
+        for (int i = 0; i < N; ++i) ncont[i] = n[i];
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) if (!(ncont[i] > 0.0)) ncont[i] = 0.0;
+    // a10 tunnel couplings: vb_eff = vb + Cbg @ vg (the Cbb cross term is identically 0)
+    const double tc_base = par[L.scal + 0];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        double vb_eff = barrier_v[b] + qd_dotN<G>(par + L.cbg + b * G, v_ext);
+        tc[b] = tc_base * exp(-par[L.alpha + b] * vb_eff);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// a9  exact k-best candidate search.
+// Minimise E(c) = (c-v')^T A (c-v') over c = floor(n_cont) + delta,
+// delta in {-1,0,1,2}^N, c >= 0, keeping the 32 smallest by (E, index) where
+// index = sum_i (delta_i+1) << 2(N-1-i).  Equivalent to the reference's scan of
+// all 4^N candidates with stable sorts (proved against the oracle in tests), but
+// done as a depth-first Schnorr-Euchner enumeration: with A = U U^T (U upper),
+// E = sum_i ((U^T d)_i)^2 and (U^T d)_i depends on d_0..d_i only, so the partial
+// sums are lower bounds and whole sub-trees are pruned against the current 32nd
+// best.  Partial sums are only used to PRUNE (with a relative safety margin);
+// every candidate that reaches a leaf gets its canonical energy, so the kept
+// list is bit-identical to the brute-force scan.
+// The top-k buffer is caller-provided strided storage (LDS on the GPU).
+// ---------------------------------------------------------------------------
+template <int N>
+struct QdSearch {
+    const double* A; int lda;        // cdd_inv (row-major, lda = G)
+    const double* U;                 // N*N row-major upper factor
+    double fl[N], vdash[N], d[N];
+    double* e; int es;               // energies, stride
+    uint16_t* id; int is;            // indices, stride
+    int count;
+    double bound, lim;
+    unsigned idx;
+    unsigned long long nodes, leaves, inserts;   // statistics (host harness only)
+};
+
+template <int N>
+QD_HD void qd_search_set_bound(QdSearch<N>& S) {
+    if (S.count == QD_K) {
+        S.bound = S.e[(QD_K - 1) * S.es];
+        S.lim = S.bound + (fabs(S.bound) * 1e-11 + 1e-300);
+    }
+}
+
+template <int N>
+QD_HD void qd_search_insert(QdSearch<N>& S, double E, unsigned idx) {
+    if (!(E < INFINITY)) return;                          // inf / NaN: treated as invalid
+    int pos;
+    if (S.count == QD_K) {
+        double el = S.e[(QD_K - 1) * S.es]; unsigned il = S.id[(QD_K - 1) * S.is];
+        if (!(E < el || (E == el && idx < il))) return;
+        pos = QD_K - 1;
+    } else {
+        pos = S.count; S.count++;
+    }
+    while (pos > 0) {
+        double ep = S.e[(pos - 1) * S.es]; unsigned ip = S.id[(pos - 1) * S.is];
+        if (!(E < ep || (E == ep && idx < ip))) break;
+        S.e[pos * S.es] = ep; S.id[pos * S.is] = (uint16_t)ip;
+        --pos;
+    }
+    S.e[pos * S.es] = E; S.id[pos * S.is] = (uint16_t)idx;
+    qd_search_set_bound(S);
+#ifndef __HIP_DEVICE_COMPILE__
+    S.inserts++;
+#endif
+}
+
+template <int N, int L>
+struct QdLevel {
+    static QD_HD void run(QdSearch<N>& S, double partial) {
+#ifndef __HIP_DEVICE_COMPILE__
+        S.nodes++;
+#endif
+        double s = 0.0;
+#pragma unroll
+        for (int j = 0; j < L; ++j) s = fma(S.U[j * N + L], S.d[j], s);
+        const double uLL = S.U[L * N + L];
+        // the four choices delta = k-1, k = 0..3
+        double dk0 = (S.fl[L] + -1.0) - S.vdash[L];
+        double dk1 = (S.fl[L] + 0.0) - S.vdash[L];
+        double dk2 = (S.fl[L] + 1.0) - S.vdash[L];
+        double dk3 = (S.fl[L] + 2.0) - S.vdash[L];
+        double t0 = fma(uLL, dk0, s), t1 = fma(uLL, dk1, s), t2 = fma(uLL, dk2, s), t3 = fma(uLL, dk3, s);
+        double a0 = fabs(t0), a1 = fabs(t1), a2 = fabs(t2), a3 = fabs(t3);
+        int k0 = 0, k1 = 1, k2 = 2, k3 = 3;
+        // sort (a, t, dk, k) ascending by a: 5-comparator network
+#define QD_CSWAP(i, j)                                                             \
+        if (a##j < a##i) {                                                         \
+            double ta = a##i; a##i = a##j; a##j = ta;                              \
+            double tt = t##i; t##i = t##j; t##j = tt;                              \
+            double td = dk##i; dk##i = dk##j; dk##j = td;                          \
+            int tk = k##i; k##i = k##j; k##j = tk;                                 \
+        }
+        QD_CSWAP(0, 1) QD_CSWAP(2, 3) QD_CSWAP(0, 2) QD_CSWAP(1, 3) QD_CSWAP(1, 2)
+#undef QD_CSWAP
+        const bool no_minus = !(S.fl[L] > 0.0);            // delta = -1 would give c < 0
+        const unsigned sh = 2u * (unsigned)(N - 1 - L);
+#define QD_VISIT(r)                                                                \
+        {                                                                          \
+            if (!(k##r == 0 && no_minus)) {                                        \
+                double pn = fma(t##r, t##r, partial);                              \
+                if (pn > S.lim) return;                                            \
+                S.d[L] = dk##r;                                                    \
+                S.idx = (S.idx & ~(3u << sh)) | ((unsigned)k##r << sh);            \
+                QdLevel<N, L + 1>::run(S, pn);                                     \
+            }                                                                      \
+        }
+        QD_VISIT(0) QD_VISIT(1) QD_VISIT(2) QD_VISIT(3)
+#undef QD_VISIT
+    }
+};
+
+template <int N>
+struct QdLevel<N, N> {
+    static QD_HD void run(QdSearch<N>& S, double) {
+#ifndef __HIP_DEVICE_COMPILE__
+        S.leaves++;
+#endif
+        double E = 0.0;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            double t = qd_dotN<N>(S.A + i * S.lda, S.d);
+            E = fma(S.d[i], t, E);
+        }
+        qd_search_insert(S, E, S.idx);
+    }
+};
+
+// Returns the number of valid candidates found (<= 32).  e/id are filled in
+// order of increasing (E, idx).
+template <int N>
+QD_HD int qd_candidates(const double* par, const double* vpp, const double* ncont,
+                        double* e, int es, uint16_t* id, int is, int32_t* fl_out,
+                        unsigned long long* stats = nullptr) {
+    const QdLayout L = qd_layout(N);
+    QdSearch<N> S;
+    S.A = par + L.cdd_inv; S.lda = N + 1; S.U = par + L.ufac;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        S.fl[i] = floor(ncont[i]); S.vdash[i] = vpp[i]; S.d[i] = 0.0;
+        fl_out[i] = (int32_t)S.fl[i];
+    }
+    S.e = e; S.es = es; S.id = id; S.is = is;
+    S.count = 0; S.bound = INFINITY; S.lim = INFINITY; S.idx = 0;
+    S.nodes = S.leaves = S.inserts = 0;
+    QdLevel<N, 0>::run(S, 0.0);
+#ifndef __HIP_DEVICE_COMPILE__
+    if (stats) { stats[0] += S.nodes; stats[1] += S.leaves; stats[2] += S.inserts; }
+#endif
+    return S.count;
+}
+
+// ---------------------------------------------------------------------------
+// a15  sensor stage of one pixel given the expectation occupations.
+// F_k = q^T A q with q = [occ - v''[:N], (Ns+k) - v''[N]], k = -5..5;
+// signal = sum over the 10 first differences of 1/((dF/gamma)^2 + 1).
+// dF is evaluated in closed form: with a = A[N][N], b = A[N,:N] . (occ - v''),
+// x_k = Ns + k - v''[N]:  F_{k+1} - F_k = 2 b + a (2 x_k + 1)   (A symmetric).
+// This is the same quantity as the reference's difference of two quadratic
+// forms without the cancellation; agreement is to round-off (float output).
+// ---------------------------------------------------------------------------
+template <int N>
+QD_HD double qd_sensor(const double* par, const double* vpp, const double* occ) {
+    constexpr int G = N + 1;
+    const QdLayout L = qd_layout(N);
+    const double* A = par + L.cdd_inv;
+    const double gamma = par[L.scal + 1];
+    const double Ns = rint(vpp[N]);                       // np.round: half to even
+    double b = 0.0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) b = fma(A[N * G + i], occ[i] - vpp[i], b);
+    const double a = A[N * G + N];
+    double s = 0.0;
+#pragma unroll
+    for (int k = -QD_NPEAK; k < QD_NPEAK; ++k) {
+        double xk = (Ns + (double)k) - vpp[N];
+        double dF = 2.0 * b + a * (2.0 * xk + 1.0);
+        double r = dF / gamma;
+        s += 1.0 / (r * r + 1.0);
+    }
+    return s;
+}
