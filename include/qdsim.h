@@ -1,0 +1,137 @@
+/*
+ * qdsim.h -- C ABI of libqdsim.so, the MI355X-native batched replacement for the
+ * per-step charge-stability simulation of QADAPT (edwindn/rl-agent-for-qubit-
+ * array-tuning).  Plain C, plain pointers and sizes, no torch types; every
+ * function returns 0 on success or a QD_ERR_* code (text via qd_last_error).
+ *
+ * The reference has no FFI (it is 100 % Python); each entry point below names
+ * the Python interface it stands in for (paths relative to the reference root).
+ * INTEGRATION.md shows the ctypes stub a maintainer adds on the reference side.
+ *
+ * Memory contract: all `*_dev` pointers are DEVICE memory owned by the caller
+ * (e.g. torch.Tensor.data_ptr()) and must stay valid until the stream work that
+ * uses them has finished.  `stream` is a hipStream_t passed as void* (NULL =
+ * default stream).  A handle is bound to one GPU and is not thread-safe (the
+ * RLlib env runner that calls the reference is single-threaded as well).
+ *
+ * Batch layout: B environments of the same n_dot (N) and resolution (R).
+ *   C = N-1 CSD channels, P = R*R pixels, G = N+1 gates (plungers + sensor).
+ *   agent order everywhere: plunger_0..plunger_{N-1}, barrier_0..barrier_{N-2}.
+ */
+#ifndef QDSIM_H
+#define QDSIM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QD_OK 0
+#define QD_ERR_ARG 1          /* bad argument / unsupported configuration        */
+#define QD_ERR_HIP 2          /* a HIP runtime call failed                        */
+#define QD_ERR_STATE 3        /* call order violated (e.g. outputs not bound)     */
+#define QD_ERR_NOMEM 4
+
+#define QD_FLAG_VALIDATE 1    /* keep per-pixel candidate records and occupations  */
+
+typedef struct qd_handle qd_handle;
+
+/* Mirrors the env_config.yaml / constructor knobs of QuantumDeviceEnv
+ * (src/qadapt/environment/env.py:38-127, 350-462, 779-787). */
+typedef struct qd_config {
+    int32_t struct_size;          /* = sizeof(qd_config), for ABI checks          */
+    int32_t n_dot;                /* N, 2..8                                       */
+    int32_t resolution;           /* R (env_config.yaml simulator.resolution)     */
+    int32_t batch;                /* B environments held by this handle            */
+    int32_t max_steps;            /* truncation horizon (simulator.max_steps)     */
+    int32_t env_chunk;            /* envs per scratch chunk, 0 = choose            */
+    int32_t flags;                /* QD_FLAG_*                                     */
+    int32_t reserved;
+    double gate_ramp_start;       /* reward.gate_ramp_start                        */
+    double gate_quadratic_start;  /* reward.gate_quadratic_start                   */
+    double barrier_ramp_start;    /* reward.barrier_ramp_start                     */
+    double kalman_prior_mean;     /* env.py:781                                    */
+    double kalman_prior_variance; /* env.py:782                                    */
+    double kalman_prior_mean_nnn; /* env.py:786                                    */
+    double kalman_variance_threshold; /* capacitance_model.variance_threshold     */
+    double kalman_process_noise;  /* capacitance_model.process_noise               */
+} qd_config;
+
+/* Sizes (in float64 elements) of the per-env parameter and state blocks whose
+ * layout is documented in csrc/qd_common.h (mirrored by qadapt_hip/layout.py). */
+int qd_param_block_doubles(int n_dot);
+int qd_state_block_doubles(int n_dot);
+/* Writes the 27 layout integers (see qadapt_hip/layout.py LAYOUT_FIELDS). */
+int qd_layout_query(int n_dot, int32_t* out27);
+
+/* QuantumDeviceEnv.__init__ (env.py:38-132): allocates device state for B envs
+ * on GPU `device`; Kalman filters start at their priors (env.py:779-787). */
+int qd_create(const qd_config* cfg, int device, qd_handle** out);
+int qd_destroy(qd_handle* h);
+const char* qd_last_error(const qd_handle* h);
+
+/* Output tensors written by qd_observe (all float32, caller-owned device memory):
+ *   global_image   [B][R][R][C]    obs["image"]            (env.py:471-509)
+ *   plunger_images [B][N][R][R][2] per-agent plunger view  (multi_agent_wrapper.py:311-350)
+ *   barrier_images [B][C][R][R][1] per-agent barrier view
+ *   voltages       [B][2N-1]       normalised gate then barrier voltages (env.py:511-532)
+ * Any pointer may be NULL to skip that output. */
+int qd_bind_outputs(qd_handle* h, float* global_image_dev, float* plunger_images_dev,
+                    float* barrier_images_dev, float* voltages_dev);
+
+/* QuantumDeviceEnv.reset's device construction (env.py:160-222) for `n` envs:
+ * uploads parameter blocks and initial state blocks (HOST pointers, n rows each)
+ * built by the host-side sampler; step counters return to 0.  The Kalman state
+ * is NOT touched (the reference never resets it, env.py:130) unless
+ * reset_kalman != 0. */
+int qd_load_episodes(qd_handle* h, const int32_t* env_ids_host, int n, const double* params_host,
+                     const double* state_host, int reset_kalman, void* stream);
+
+/* QuantumDeviceEnv.step lines env.py:260-285: clip + rescale the actions
+ * [B][2N-1] (gates then barriers, float32), reward against the PREVIOUS ground
+ * truth, step counter and truncation flag.  rewards_dev [B][2N-1] float64,
+ * truncated_dev [B] uint8. */
+int qd_apply_actions(qd_handle* h, const float* actions_dev, double* rewards_dev,
+                     uint8_t* truncated_dev, void* stream);
+
+/* QarrayBaseClass._get_obs + QuantumDeviceEnv._normalise_obs +
+ * MultiAgentEnvWrapper._extract_agent_observation
+ * (qarray_base_class.py:171-229, env.py:471-534, multi_agent_wrapper.py:311-383)
+ * for the listed envs (env_ids_dev == NULL: all B).  Writes the bound outputs. */
+int qd_observe(qd_handle* h, const int32_t* env_ids_dev, int n, void* stream);
+
+/* QuantumDeviceEnv._update_virtual_gate_matrix (env.py:537-622) with the CNN's
+ * outputs supplied by the caller: values/log_vars [B][C][3] float32 (indexed by
+ * env id, not by list position).  Kalman update (KalmanUpdater.py:92-213), VGM
+ * (qarray_base_class.py:904-942) and, if recompute_ground_truth != 0, the new
+ * ground truth (env.py:298-305; reset() skips this, env.py:233). */
+int qd_update_capacitance(qd_handle* h, const int32_t* env_ids_dev, int n, const float* values_dev,
+                          const float* log_vars_dev, int recompute_ground_truth, void* stream);
+
+/* One whole QuantumDeviceEnv.step for all B envs = qd_apply_actions +
+ * qd_observe + qd_update_capacitance(recompute_ground_truth = 1). */
+int qd_step(qd_handle* h, const float* actions_dev, const float* values_dev,
+            const float* log_vars_dev, double* rewards_dev, uint8_t* truncated_dev, void* stream);
+
+/* Validation / checkpoint access (blocking copies to HOST memory).
+ *   state_host [B][qd_state_block_doubles], steps_host [B] int32
+ *   raw_host   [B][C][P] float64 unnormalised sensor signal of the last observe
+ *   plohi_host [B][2]    the 0.5 / 99.5 percentiles used
+ *   occ_host   [B][C][P][N] float64 expectation occupations   (QD_FLAG_VALIDATE)
+ *   states_host [B][C][P][32][N] int32 kept charge states      (QD_FLAG_VALIDATE) */
+int qd_get_state(qd_handle* h, double* state_host, int32_t* steps_host);
+int qd_set_state(qd_handle* h, const double* state_host, const int32_t* steps_host);
+int qd_get_raw(qd_handle* h, double* raw_host, double* plohi_host);
+int qd_get_occupations(qd_handle* h, double* occ_host);
+int qd_get_candidates(qd_handle* h, int32_t* states_host);
+
+/* Timing hook for bench.py: runs `iters` back-to-back launches of the dominant
+ * kernel (ground state) on the current data and returns the mean duration in
+ * milliseconds measured with HIP events on `stream`. */
+int qd_time_ground_kernel(qd_handle* h, int iters, float* mean_ms, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QDSIM_H */

@@ -1,0 +1,403 @@
+// qd_groundstate.h -- wave-level ground state of H = diag(F) + H_t over the 32
+// kept charge states of one pixel (reference:
+// hamiltonian_build.py:12-45, 75-137, 460-483 and ground_state.py:149-162).
+//
+// Mapping: ONE PIXEL PER HALF-WAVE (32 lanes), ONE BASIS STATE PER LANE; a
+// 64-lane wavefront works on two pixels at once.  All cross-lane traffic stays
+// inside a half (ds_bpermute via __shfl(..., 32)) or goes through a small
+// per-wave LDS area.
+//
+// Algorithm (numerics validated against numpy.linalg.eigh in
+// tests/proto_groundstate.py, which this file follows step by step):
+//   1. occupations and free energy F_m of lane m's state (canonical energy()).
+//   2. hop neighbours: states i,j are coupled over the adjacent pair d iff
+//      s_j - s_i = -+e_d +-e_{d+1}.  With 4-bit-spaced delta codes that is
+//      |code_j - code_i| == 15 << 4q.  H_ij = -t_d sqrt(n_from (n_to + 1)) with
+//      the occupations of the ROW state (hamiltonian_build.py:125-131).
+//   3. connected components of that graph (hopping conserves total charge, so H
+//      is block diagonal; the padding copies of |0..0> are always isolated).
+//   4. Gershgorin pruning: a component whose lower bound min(F - sum|H_ij|)
+//      exceeds min F overall cannot hold the ground state.
+//   5. every surviving component in parallel: Lanczos from the all-ones vector
+//      (H_t <= 0 off-diagonal => the ground vector of an irreducible block is
+//      positive, so the start vector always overlaps it); at most `size` steps.
+//      The tridiagonal T lives one row per member lane.
+//   6. lowest eigenvalue of T by multisection on the Sturm count (each member
+//      lane tests its own shift), eigenvector of T by inverse iteration with
+//      the SPD factorisation at the lower bracket end.
+//   7. second Lanczos pass accumulates x = Q y (no basis storage).
+//   8. the component with the lowest eigenvalue wins; <n> = sum_m x_m^2 s_m.
+// Solving block by block is at least as accurate as one dense 32x32 eigh (no
+// rounding-level mixing of different charge sectors).
+#pragma once
+#include "qd_pixel.h"
+
+#if defined(__HIPCC__)
+
+#define QD_NBMAX 14                 // a state has at most 2*(N-1) hop neighbours
+
+struct QdWaveLds {
+    double coef[QD_NBMAX][64];      // H_ij of neighbour slot s of lane
+    unsigned char nidx[QD_NBMAX][64];
+    double buf[64];                 // publish buffer for per-component reductions
+    double al[64], be[64];          // T: alpha_r / beta_r at the r-th member lane
+    double rd[64], lf[64], yv[64];  // inverse iteration: 1/d_i, l_i, y_i at member slots
+};
+
+__device__ __forceinline__ unsigned qd_half_ballot(bool p) {
+    unsigned long long b = __ballot(p);
+    return (unsigned)(b >> (threadIdx.x & 32));
+}
+__device__ __forceinline__ double qd_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+__device__ __forceinline__ double qd_half_min(double v) {
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o, 32));
+    return v;
+}
+__device__ __forceinline__ double qd_half_sum(double v) {
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 32);
+    return v;
+}
+__device__ __forceinline__ int qd_wave_max_int(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// per-component (segment) reductions through the LDS publish buffer.  `seg` is
+// the member mask (bit b = lane b of my half), hb = 0 or 32, smax = wave-wide
+// max member count.  Summation runs over members in ascending lane order, so
+// every member gets bit-identical results.
+__device__ __forceinline__ double qd_seg_sum(double v, unsigned seg, int smax, volatile double* buf, int hb) {
+    buf[threadIdx.x & 63] = v;
+    __builtin_amdgcn_wave_barrier();
+    double acc = 0.0;
+    unsigned mm = seg;
+    for (int it = 0; it < smax; ++it) {
+        if (mm) { int b = __builtin_ctz(mm); mm &= mm - 1; acc += buf[hb + b]; }
+    }
+    __builtin_amdgcn_wave_barrier();
+    return acc;
+}
+__device__ __forceinline__ double qd_seg_min(double v, unsigned seg, int smax, volatile double* buf, int hb) {
+    buf[threadIdx.x & 63] = v;
+    __builtin_amdgcn_wave_barrier();
+    double acc = INFINITY;
+    unsigned mm = seg;
+    for (int it = 0; it < smax; ++it) {
+        if (mm) { int b = __builtin_ctz(mm); mm &= mm - 1; acc = fmin(acc, buf[hb + b]); }
+    }
+    __builtin_amdgcn_wave_barrier();
+    return acc;
+}
+__device__ __forceinline__ double qd_seg_max(double v, unsigned seg, int smax, volatile double* buf, int hb) {
+    return -qd_seg_min(-v, seg, smax, buf, hb);
+}
+
+// Sturm count (number of eigenvalues < lam) of the k x k tridiagonal whose rows
+// live at the member lanes of `seg` (ascending order).
+__device__ __forceinline__ int qd_sturm(double lam, unsigned seg, int k, int kmax,
+                                        volatile const double* al, volatile const double* be, int hb) {
+    unsigned mm = seg;
+    int cnt = 0;
+    double d = 1.0, bprev = 0.0;
+    for (int i = 0; i < kmax; ++i) {
+        if (i < k) {
+            int b = __builtin_ctz(mm); mm &= mm - 1;
+            double a = al[hb + b];
+            double q = (i == 0) ? 0.0 : (bprev * bprev) * qd_rcp(d);
+            d = (a - lam) - q;
+            if (d == 0.0) d = -1e-300;
+            cnt += d < 0.0;
+            bprev = be[hb + b];
+        }
+    }
+    return cnt;
+}
+
+// One pixel per half-wave.  A: cdd_inv (row-major, lda = N+1) readable by all
+// lanes (LDS).  rec: this half's pixel record.  On return every lane of the half
+// holds the expectation occupations occ[0..N) and the ground energy.
+template <int N>
+__device__ void qd_ground_pixel(const double* __restrict__ A, const QdPixelRec* __restrict__ rec,
+                                QdWaveLds& W, double* occ, double* lam_out) {
+    constexpr int G = N + 1;
+    const int lane = threadIdx.x & 63;
+    const int m = lane & 31;
+    const int hb = lane & 32;
+    const unsigned lt = (1u << m) - 1u;
+    volatile double* buf = W.buf;
+
+    // ---- 1. my state -------------------------------------------------------
+    const int nvalid = rec->nvalid;
+    const bool valid = m < nvalid;
+    const unsigned code = valid ? (unsigned)rec->idx[m] : 0u;
+    int n[N];
+    double dd[N];
+    unsigned ecode = 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const int dig = (code >> (2 * (N - 1 - i))) & 3;
+        n[i] = valid ? rec->fl[i] + dig - 1 : 0;
+        dd[i] = (double)n[i] - rec->vpp[i];
+        ecode |= (unsigned)dig << (4 * (N - 1 - i));
+    }
+    double F = 0.0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        double t = qd_dotN<N>(A + i * G, dd);
+        F = fma(dd[i], t, F);
+    }
+
+    // ---- 2. hop neighbours -------------------------------------------------
+    unsigned nbrmask = 0;
+    for (int j = 0; j < 32; ++j) {
+        const unsigned cj = __shfl(ecode, j, 32);
+        const int Y = (int)cj - (int)ecode;
+        const unsigned ay = (unsigned)(Y < 0 ? -Y : Y);
+        const int tz = ay ? __builtin_ctz(ay) : 0;
+        const bool hop = ay != 0 && (ay >> tz) == 15u && (tz & 3) == 0;
+        if (hop && valid && j < nvalid) nbrmask |= 1u << j;
+    }
+    const int cnt = __popc(nbrmask);
+    const int maxcnt = qd_wave_max_int(cnt);
+    {
+        unsigned rem = nbrmask;
+        for (int s = 0; s < maxcnt; ++s) {
+            const bool has = rem != 0;
+            const int j = has ? __builtin_ctz(rem) : m;
+            rem &= rem - 1;
+            const unsigned cj = __shfl(ecode, j, 32);
+            double c = 0.0;
+            if (has) {
+                const int Y = (int)cj - (int)ecode;
+                const unsigned ay = (unsigned)(Y < 0 ? -Y : Y);
+                const int q = __builtin_ctz(ay) >> 2;
+                const int d = N - 2 - q;                   // adjacent pair (d, d+1)
+                int nd = 0, nd1 = 0;
+#pragma unroll
+                for (int i = 0; i < N; ++i) { if (i == d) nd = n[i]; if (i == d + 1) nd1 = n[i]; }
+                const double t = rec->tc[d];
+                // Y < 0: s_j = s_i - e_d + e_{d+1} (forward); else backward
+                const double prod = (Y < 0) ? (double)nd * ((double)nd1 + 1.0)
+                                            : (double)nd1 * ((double)nd + 1.0);
+                c = -t * sqrt(prod);
+            }
+            W.coef[s][lane] = c;
+            W.nidx[s][lane] = (unsigned char)j;
+        }
+    }
+
+    // ---- 3. connected components (reach masks) -----------------------------
+    unsigned seg = 1u << m;
+    if (valid) seg |= nbrmask;
+    for (int guard = 0; guard < 32; ++guard) {
+        unsigned nw = seg;
+        for (int s = 0; s < maxcnt; ++s) {
+            const unsigned r2 = __shfl(seg, (int)W.nidx[s][lane], 32);
+            if (s < cnt) nw |= r2;
+        }
+        const bool changed = nw != seg;
+        seg = nw;
+        if (!__any(changed)) break;
+    }
+    const int ssz = __popc(seg);
+    const int r = __popc(seg & lt);                        // my index inside the component
+    const int smax = qd_wave_max_int(ssz);
+
+    // ---- 4. Gershgorin pruning ---------------------------------------------
+    double radius = 0.0;
+    for (int s = 0; s < maxcnt; ++s) radius += fabs(W.coef[s][lane]);
+    const double upper_all = qd_half_min(F);
+    const double comp_lower = qd_seg_min(F - radius, seg, smax, buf, hb);
+    const bool active = comp_lower <= upper_all;
+
+    // ---- 5. Lanczos pass 1: T ----------------------------------------------
+    const bool solve = active && ssz > 1;
+    const double q0 = solve ? 1.0 / sqrt((double)ssz) : 0.0;
+    double q = q0, qp = 0.0, bp = 0.0, anorm = 0.0;
+    double al_mine = F, be_mine = 0.0;                     // singleton: T = [F]
+    int k = solve ? 0 : 1;
+    bool done = !solve;
+    const int jmax = qd_wave_max_int(solve ? ssz : 0);
+    for (int j = 0; j < jmax; ++j) {
+        if (!__any(!done)) break;
+        double w = F * q;
+        for (int s = 0; s < maxcnt; ++s) {
+            const double qj = __shfl(q, (int)W.nidx[s][lane], 32);
+            w = fma(W.coef[s][lane], qj, w);
+        }
+        const double a = qd_seg_sum(q * w, seg, smax, buf, hb);
+        w = w - a * q - bp * qp;
+        const double b = sqrt(qd_seg_sum(w * w, seg, smax, buf, hb));
+        if (!done) {
+            anorm = fmax(anorm, fmax(fabs(a), b));
+            if (r == j) { al_mine = a; be_mine = b; }
+            k = j + 1;
+            if (j + 1 >= ssz || !(b > 1e-13 * anorm)) {
+                done = true;
+                if (r == j) be_mine = 0.0;
+            } else {
+                qp = q; bp = b; q = w * qd_rcp(b);
+            }
+        }
+    }
+    W.al[lane] = al_mine;
+    W.be[lane] = (r < k - 1) ? be_mine : 0.0;
+    __builtin_amdgcn_wave_barrier();
+    volatile const double* al = W.al;
+    volatile const double* be = W.be;
+    const int kmax = qd_wave_max_int(k);
+
+    // ---- 6a. lowest eigenvalue of T: multisection on the Sturm count --------
+    // Gershgorin bracket from the rows owned by member lanes r < k.
+    double lo, hi;
+    {
+        const unsigned below = seg & lt;
+        const int prev = below ? 31 - __builtin_clz(below) : m;
+        const double bprev = (r > 0 && r < k) ? be[hb + prev] : 0.0;
+        const double bme = (r < k - 1) ? be_mine : 0.0;
+        const double g = (r < k) ? al_mine - fabs(bprev) - fabs(bme) : INFINITY;
+        lo = qd_seg_min(g, seg, smax, buf, hb);
+        hi = qd_seg_min((r < k) ? al_mine : INFINITY, seg, smax, buf, hb);
+        const double sc = fmax(fabs(lo), fabs(hi));
+        lo -= 4e-16 * sc + 1e-300;
+    }
+    // Invariant: count(lo) == 0 and lambda0 <= hi.  Each member lane tests one
+    // interior point per round, so the bracket shrinks by (size+1) per round.
+    const double lo0 = lo;
+    bool stalled = false;
+    for (int round = 0; round < 64; ++round) {
+        const double width = hi - lo;
+        const bool conv = stalled || (k <= 1) || !(width > 4.5e-16 * fmax(fabs(lo), fabs(hi)));
+        if (!__any(!conv)) break;
+        const double h = width / (double)(ssz + 1);
+        const double lam_r = fma((double)(r + 1), h, lo);
+        const int c = qd_sturm(lam_r, seg, k, kmax, al, be, hb);
+        const unsigned neg = qd_half_ballot(c >= 1 && !conv) & seg;
+        if (!conv) {
+            int first = ssz;                                // first member whose point has count >= 1
+            if (neg) first = __popc(seg & ((1u << __builtin_ctz(neg)) - 1u));
+            const double nlo = (first == 0) ? lo : fma((double)first, h, lo);
+            const double nhi = (first == ssz) ? hi : fma((double)(first + 1), h, lo);
+            if (!(nlo > lo) && !(nhi < hi)) stalled = true;  // no representable progress
+            else { lo = fmax(lo, nlo); hi = fmin(hi, fmax(nhi, lo)); }
+        }
+    }
+    (void)lo0;
+    // component-uniform eigenvalue: T = [alpha_0] when k <= 1 (row 0 = first member)
+    const double lam = (k <= 1) ? al[hb + __builtin_ctz(seg)] : hi;
+
+    // ---- 6b. eigenvector of T: inverse iteration, SPD factorisation at sigma = lo
+    // (T - lo) = L D L^T.  Every member lane runs the same serial recurrences and
+    // writes identical values: rd[row i] = 1/d_i, lf[row i] = l_{i-1}, yv[row i] = y_i.
+    {
+        const double sig = lo;
+        const double tiny = 1e-300 + 1e-18 * fmax(fabs(lo), fabs(hi));
+        unsigned mm = seg;
+        double d = 1.0, bprev = 0.0;
+        for (int i = 0; i < kmax; ++i) {
+            if (i < k) {
+                const int b = __builtin_ctz(mm); mm &= mm - 1;
+                const double a = al[hb + b];
+                double di = a - sig;
+                if (i > 0) {
+                    const double l = bprev * qd_rcp(d);
+                    di = di - l * bprev;
+                    W.lf[hb + b] = l;
+                }
+                if (!(di > tiny)) di = tiny;
+                d = di;
+                W.rd[hb + b] = qd_rcp(d);
+                bprev = be[hb + b];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int iter = 0; iter < 2; ++iter) {
+            // forward  L z = rhs, then w = D^-1 z
+            unsigned m2 = seg;
+            double zprev = 0.0;
+            for (int i = 0; i < kmax; ++i) {
+                if (i < k) {
+                    const int b = __builtin_ctz(m2); m2 &= m2 - 1;
+                    const double rhs = (iter == 0) ? 1.0 : W.yv[hb + b];
+                    const double z = (i == 0) ? rhs : rhs - W.lf[hb + b] * zprev;
+                    W.yv[hb + b] = z * W.rd[hb + b];
+                    zprev = z;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            // backward  L^T y = w : y_i = w_i - l_i y_{i+1}; walk the first k members from the top
+            unsigned m3 = seg;
+            for (int i = ssz; i > k; --i) m3 &= ~(1u << (31 - __builtin_clz(m3)));
+            double ynext = 0.0, lnext = 0.0, nrm = 0.0;
+            for (int i = kmax - 1; i >= 0; --i) {
+                if (i < k) {
+                    const int b = 31 - __builtin_clz(m3); m3 &= ~(1u << b);
+                    const double y = W.yv[hb + b] - lnext * ynext;      // lnext = l_i (0 for the last row)
+                    W.yv[hb + b] = y;
+                    nrm = fma(y, y, nrm);
+                    ynext = y;
+                    lnext = (i > 0) ? W.lf[hb + b] : 0.0;               // l_{i-1}
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            const double inv = (nrm > 0.0) ? 1.0 / sqrt(nrm) : 1.0;
+            unsigned m4 = seg;
+            for (int i = 0; i < kmax; ++i) {
+                if (i < k) { const int b = __builtin_ctz(m4); m4 &= m4 - 1; W.yv[hb + b] = W.yv[hb + b] * inv; }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+
+    // ---- 7. Lanczos pass 2: x = sum_j y_j q_j -------------------------------
+    double x = solve ? 0.0 : 1.0;
+    {
+        double q2 = q0, qp2 = 0.0, bp2 = 0.0;
+        bool done2 = !solve;
+        unsigned mm = seg;
+        for (int j = 0; j < jmax; ++j) {
+            if (!__any(!done2)) break;
+            double yj = 0.0;
+            if (!done2) { const int b = __builtin_ctz(mm); mm &= mm - 1; yj = W.yv[hb + b]; }
+            double w = F * q2;
+            for (int s = 0; s < maxcnt; ++s) {
+                const double qj = __shfl(q2, (int)W.nidx[s][lane], 32);
+                w = fma(W.coef[s][lane], qj, w);
+            }
+            const double a = qd_seg_sum(q2 * w, seg, smax, buf, hb);
+            w = w - a * q2 - bp2 * qp2;
+            const double b = sqrt(qd_seg_sum(w * w, seg, smax, buf, hb));
+            if (!done2) {
+                x = fma(yj, q2, x);
+                if (j + 1 >= k) done2 = true;
+                else { qp2 = q2; bp2 = b; q2 = w * qd_rcp(b); }
+            }
+        }
+    }
+    if (solve) {
+        const double nx = qd_seg_sum(x * x, seg, smax, buf, hb);
+        x = x * (1.0 / sqrt(nx));
+    }
+
+    // ---- 8. pick the lowest component, expectation occupations --------------
+    const double mylam = active ? lam : INFINITY;
+    const double best = qd_half_min(mylam);
+    // tie between components: lowest root lane wins (deterministic)
+    const unsigned win = qd_half_ballot(mylam == best);
+    const int wroot = __builtin_ctz(win);
+    const unsigned wseg = __shfl(seg, wroot, 32);
+    const double p = ((wseg >> m) & 1u) ? x * x : 0.0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) occ[i] = qd_half_sum(p * (double)n[i]);
+    *lam_out = best;
+}
+
+#endif  // __HIPCC__

@@ -1,0 +1,59 @@
+// qd_hosttest.cpp -- CPU-only TEST HARNESS around the __host__ __device__ code
+// in qd_pixel.h.  It exists so the per-pixel device code (sweep, continuous
+// state, exact k-best search, sensor stage) can be checked against the oracle
+// in the no-GPU test tier.  It is NOT part of the product: nothing in
+// qadapt_hip loads it, and it contains no ground-state solver (that stage only
+// exists as HIP code).  Built by tests via csrc/Makefile target hosttest.
+#include <string.h>
+#include "qd_pixel.h"
+
+template <int N>
+static int run_front(const double* par, const double* st, int ch, int R, int p0, int p1,
+                     int32_t* states, int32_t* floors, double* vpp_out, double* tc_out,
+                     int32_t* nvalid, unsigned long long* stats) {
+    constexpr int G = N + 1, NB = N - 1, V = 2 * N;
+    for (int p = p0; p < p1; ++p) {
+        int y = p / R, x = p % R;
+        double v_ext[V], vpp[G], ncont[N], tc[NB > 0 ? NB : 1];
+        qd_pixel_front<N>(par, st, ch, R, x, y, v_ext, vpp, ncont, tc);
+        double e[QD_K]; uint16_t id[QD_K]; int32_t fl[N];
+        int nv = qd_candidates<N>(par, vpp, ncont, e, 1, id, 1, fl, stats);
+        static const int DELTA[4] = {-1, 0, 1, 2};
+        for (int m = 0; m < QD_K; ++m)
+            for (int i = 0; i < N; ++i) {
+                int dig = (id[m] >> (2 * (N - 1 - i))) & 3;
+                states[((size_t)p * QD_K + m) * N + i] = m < nv ? fl[i] + DELTA[dig] : 0;
+            }
+        memcpy(floors + (size_t)p * N, fl, sizeof(int32_t) * N);
+        memcpy(vpp_out + (size_t)p * G, vpp, sizeof(double) * G);
+        memcpy(tc_out + (size_t)p * NB, tc, sizeof(double) * NB);
+        nvalid[p] = nv;
+    }
+    return 0;
+}
+
+extern "C" int qdh_front(int N, const double* par, const double* st, int ch, int R, int p0, int p1,
+                         int32_t* states, int32_t* floors, double* vpp_out, double* tc_out,
+                         int32_t* nvalid, unsigned long long* stats) {
+    switch (N) {
+#define C(n) case n: return run_front<n>(par, st, ch, R, p0, p1, states, floors, vpp_out, tc_out, nvalid, stats);
+        C(2) C(3) C(4) C(5) C(6) C(7) C(8)
+#undef C
+    }
+    return 1;
+}
+
+extern "C" double qdh_sensor(int N, const double* par, const double* vpp, const double* occ) {
+    switch (N) {
+#define C(n) case n: return qd_sensor<n>(par, vpp, occ);
+        C(2) C(3) C(4) C(5) C(6) C(7) C(8)
+#undef C
+    }
+    return -1.0;
+}
+
+extern "C" void qdh_layout(int N, int* out) {
+    QdLayout L = qd_layout(N);
+    memcpy(out, &L, sizeof(L));
+}
+extern "C" int qdh_layout_ints() { return (int)(sizeof(QdLayout) / sizeof(int)); }

@@ -1,0 +1,491 @@
+// qd_kernels.h -- the HIP kernels of the batched env step (gfx950, wave64).
+//
+//   qd_k_actions     a2, a3   one thread per env
+//   qd_k_candidates  a5, a8, a9, a10   one pixel per lane, exact k-best search
+//   qd_k_ground      a11-a13, a15      one pixel per half-wave (qd_groundstate.h)
+//   qd_k_percentile  a17 (exact 0.5 / 99.5 percentiles, radix select)
+//   qd_k_write_obs   a17, a22 normalise + global / per-agent images + voltages
+//   qd_k_update      a19, a20, a21     Kalman, VGM (SVD pseudo-inverse), ground truth
+//
+// Data layout in HBM (all per handle):
+//   params [B][L.size] f64, state [B][L.s_size] f64, steps [B] i32
+//   recs   [chunk][C][P] QdPixelRec (scratch between candidates and ground kernels)
+//   zraw   [B][C][P] f64 raw sensor signal,  plohi [B][2] f64
+#pragma once
+#include "qd_groundstate.h"
+
+#if defined(__HIPCC__)
+
+// ---------------------------------------------------------------------------
+// a2 + a3: actions -> voltages, reward vs previous ground truth, step counter
+// (env.py:260-285, 350-462, 861-876)
+// ---------------------------------------------------------------------------
+struct QdRewardCfg { double gate_ramp_start, gate_quadratic_start, barrier_ramp_start; int max_steps; };
+
+template <int N>
+__global__ void qd_k_actions(int B, const double* __restrict__ params, double* __restrict__ state,
+                             int* __restrict__ steps, const float* __restrict__ actions,
+                             double* __restrict__ rewards, uint8_t* __restrict__ truncated, QdRewardCfg rc) {
+    constexpr int NB = N - 1, G = N + 1, V = 2 * N, NA = 2 * N - 1;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= B) return;
+    const QdLayout L = qd_layout(N);
+    const double* par = params + (size_t)e * L.size;
+    double* st = state + (size_t)e * L.s_size;
+    const float* act = actions + (size_t)e * NA;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        float a = act[i];
+        a = fminf(fmaxf(a, -1.0f), 1.0f);
+        const float h = (a + 1.0f) / 2.0f;                       // float32, as the reference
+        const double lo = par[L.pmin + i], hi = par[L.pmax + i];
+        const double v = (double)h * (hi - lo) + lo;
+        st[L.s_gate_v + i] = v;
+        const double dist = fabs(st[L.s_gate_gt + i] - v) * fabs(par[L.cgd + i * V + i]);
+        double r;
+        if (dist >= rc.gate_ramp_start) r = 0.0;
+        else if (dist > rc.gate_quadratic_start)
+            r = 0.5 * ((rc.gate_ramp_start - dist) / (rc.gate_ramp_start - rc.gate_quadratic_start));
+        else r = 0.5 + 0.5 * 1.0;                                // gate_curve_type "constant"
+        if (rewards) rewards[(size_t)e * NA + i] = fmin(fmax(r, 0.0), 1.0);
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        float a = act[N + b];
+        a = fminf(fmaxf(a, -1.0f), 1.0f);
+        const float h = (a + 1.0f) / 2.0f;
+        const double lo = par[L.bmin + b], hi = par[L.bmax + b];
+        const double v = (double)h * (hi - lo) + lo;
+        st[L.s_barrier_v + b] = v;
+        const double dist = fabs(st[L.s_barrier_gt + b] - v) * par[L.alpha + b];
+        double r = (dist >= rc.barrier_ramp_start) ? 0.0 : (rc.barrier_ramp_start - dist) / rc.barrier_ramp_start;
+        if (rewards) rewards[(size_t)e * NA + N + b] = fmin(fmax(r, 0.0), 1.0);
+    }
+    const int s = steps[e] + 1;
+    steps[e] = s;
+    if (truncated) truncated[e] = s >= rc.max_steps ? 1 : 0;
+    (void)G;
+}
+
+// ---------------------------------------------------------------------------
+// a5/a8/a9/a10: one pixel per lane.  grid = (ceil(P/BLOCK), C, n_env).
+// ---------------------------------------------------------------------------
+#define QD_CAND_BLOCK 128
+
+template <int N>
+__global__ void __launch_bounds__(QD_CAND_BLOCK)
+qd_k_candidates(const int* __restrict__ env_ids, int env_base, int R, const double* __restrict__ params,
+                const double* __restrict__ state, QdPixelRec* __restrict__ recs) {
+    constexpr int G = N + 1, NB = N - 1, V = 2 * N;
+    const QdLayout L = qd_layout(N);
+    const int slot = blockIdx.z;
+    const int e = env_ids ? env_ids[env_base + slot] : env_base + slot;
+    const int ch = blockIdx.y;
+    const int P = R * R;
+    const int p = blockIdx.x * QD_CAND_BLOCK + threadIdx.x;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    double* spar = (double*)smem_raw;                         // L.size
+    double* sst = spar + L.size;                              // L.s_size
+    double* se = sst + L.s_size;                              // [32][BLOCK]
+    uint16_t* sid = (uint16_t*)(se + QD_K * QD_CAND_BLOCK);   // [32][BLOCK]
+    for (int i = threadIdx.x; i < L.size; i += QD_CAND_BLOCK) spar[i] = params[(size_t)e * L.size + i];
+    for (int i = threadIdx.x; i < L.s_size; i += QD_CAND_BLOCK) sst[i] = state[(size_t)e * L.s_size + i];
+    __syncthreads();
+    if (p >= P) return;
+    const int y = p / R, x = p - y * R;
+    double v_ext[V], vpp[G], ncont[N], tc[NB];
+    qd_pixel_front<N>(spar, sst, ch, R, x, y, v_ext, vpp, ncont, tc);
+    int32_t fl[N];
+    const int nv = qd_candidates<N>(spar, vpp, ncont, se + threadIdx.x, QD_CAND_BLOCK,
+                                    sid + threadIdx.x, QD_CAND_BLOCK, fl);
+    QdPixelRec* rec = recs + ((size_t)slot * (N - 1) + ch) * P + p;
+#pragma unroll
+    for (int m = 0; m < QD_K; ++m) rec->idx[m] = m < nv ? sid[m * QD_CAND_BLOCK + threadIdx.x] : 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) rec->fl[i] = fl[i];
+    rec->nvalid = nv;
+#pragma unroll
+    for (int i = 0; i < G; ++i) rec->vpp[i] = vpp[i];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) rec->tc[b] = tc[b];
+}
+
+// ---------------------------------------------------------------------------
+// a11-a13 + a15: one pixel per half-wave.  grid = (ceil(P/PPB), C, n_env).
+// ---------------------------------------------------------------------------
+#define QD_GS_BLOCK 256
+#define QD_GS_PPB 64            // pixels per block: 8 half-waves x 8 pixels
+
+template <int N>
+__global__ void __launch_bounds__(QD_GS_BLOCK)
+qd_k_ground(const int* __restrict__ env_ids, int env_base, int R, const double* __restrict__ params,
+            const QdPixelRec* __restrict__ recs, double* __restrict__ zraw, double* __restrict__ occ_out) {
+    constexpr int G = N + 1;
+    const QdLayout L = qd_layout(N);
+    const int slot = blockIdx.z;
+    const int e = env_ids ? env_ids[env_base + slot] : env_base + slot;
+    const int ch = blockIdx.y;
+    const int P = R * R;
+    __shared__ double sA[G * G + 2];
+    __shared__ QdWaveLds sW[QD_GS_BLOCK / 64];
+    const double* par = params + (size_t)e * L.size;
+    for (int i = threadIdx.x; i < G * G; i += QD_GS_BLOCK) sA[i] = par[L.cdd_inv + i];
+    if (threadIdx.x == 0) sA[G * G] = par[L.scal + 1];       // gamma
+    __syncthreads();
+    const int half = threadIdx.x >> 5;                       // 0..7
+    QdWaveLds& W = sW[threadIdx.x >> 6];
+    const QdPixelRec* rbase = recs + ((size_t)slot * (N - 1) + ch) * P;
+    const int p0 = blockIdx.x * QD_GS_PPB;
+    for (int it = 0; it < QD_GS_PPB / 8; ++it) {
+        const int p = p0 + it * 8 + half;
+        // both halves of a wave run in lock step: clamp instead of exiting
+        const int pc = p < P ? p : P - 1;
+        if (p0 + it * 8 >= P) break;                         // uniform for the block
+        const QdPixelRec* rec = rbase + pc;
+        double occ[N], lam;
+        qd_ground_pixel<N>(sA, rec, W, occ, &lam);
+        if ((threadIdx.x & 31) == 0 && p < P) {
+            // sensor stage (closed-form differences, qd_pixel.h)
+            const double Ns = rint(rec->vpp[N]);
+            double b = 0.0;
+#pragma unroll
+            for (int i = 0; i < N; ++i) b = fma(sA[N * G + i], occ[i] - rec->vpp[i], b);
+            const double a = sA[N * G + N];
+            const double gamma = sA[G * G];
+            double s = 0.0;
+#pragma unroll
+            for (int k = -QD_NPEAK; k < QD_NPEAK; ++k) {
+                const double xk = (Ns + (double)k) - rec->vpp[N];
+                const double dF = 2.0 * b + a * (2.0 * xk + 1.0);
+                const double rr = dF / gamma;
+                s += 1.0 / (rr * rr + 1.0);
+            }
+            zraw[((size_t)e * (N - 1) + ch) * P + p] = s;
+            if (occ_out) {
+#pragma unroll
+                for (int i = 0; i < N; ++i) occ_out[(((size_t)e * (N - 1) + ch) * P + p) * N + i] = occ[i];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// a17: exact percentiles (numpy 'linear' method) of the C*P raw values of one
+// env by MSB-first radix select on order-preserving 64-bit keys.
+// One block per env.  plohi[e] = (p_low, p_high); NaN anywhere -> (NaN, NaN).
+// ---------------------------------------------------------------------------
+#define QD_PCT_BLOCK 1024
+
+__device__ __forceinline__ unsigned long long qd_key(double x) {
+    unsigned long long u = (unsigned long long)__double_as_longlong(x);
+    return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double qd_unkey(unsigned long long k) {
+    unsigned long long u = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+    return __longlong_as_double((long long)u);
+}
+
+// value of rank `t` (0-based) among n keys
+__device__ unsigned long long qd_radix_select(const double* __restrict__ z, long n, long t, unsigned* hist /*256*/,
+                                              unsigned long long* sh_prefix, long* sh_t) {
+    unsigned long long prefix = 0, mask = 0;
+    for (int pass = 7; pass >= 0; --pass) {
+        for (int i = threadIdx.x; i < 256; i += blockDim.x) hist[i] = 0;
+        __syncthreads();
+        const int shift = pass * 8;
+        for (long i = threadIdx.x; i < n; i += blockDim.x) {
+            const unsigned long long k = qd_key(z[i]);
+            if ((k & mask) == prefix) atomicAdd(&hist[(k >> shift) & 255], 1u);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            long acc = 0; int b = 0;
+            for (; b < 256; ++b) { if (acc + (long)hist[b] > t) break; acc += hist[b]; }
+            if (b > 255) b = 255;
+            *sh_prefix = prefix | ((unsigned long long)b << shift);
+            *sh_t = t - acc;
+        }
+        __syncthreads();
+        prefix = *sh_prefix; t = *sh_t;
+        mask |= 0xffull << shift;
+        __syncthreads();
+    }
+    return prefix;
+}
+
+__device__ __forceinline__ double qd_lerp(double a, double b, double t) {
+    const double diff = b - a;
+    double r = a + diff * t;
+    if (t >= 0.5) r = b - diff * (1.0 - t);
+    return r;
+}
+
+__global__ void __launch_bounds__(QD_PCT_BLOCK)
+qd_k_percentile(const int* __restrict__ env_ids, long n, const double* __restrict__ zraw, double* __restrict__ plohi) {
+    const int e = env_ids ? env_ids[blockIdx.x] : blockIdx.x;
+    const double* z = zraw + (size_t)e * n;
+    __shared__ unsigned hist[256];
+    __shared__ unsigned long long sh_prefix;
+    __shared__ long sh_t;
+    __shared__ unsigned long long sh_red[QD_PCT_BLOCK / 64];
+    __shared__ int sh_nan;
+    if (threadIdx.x == 0) sh_nan = 0;
+    __syncthreads();
+    int has_nan = 0;
+    for (long i = threadIdx.x; i < n; i += blockDim.x) has_nan |= (z[i] != z[i]);
+    if (has_nan) sh_nan = 1;
+    __syncthreads();
+    if (sh_nan) { if (threadIdx.x == 0) { plohi[2 * e] = NAN; plohi[2 * e + 1] = NAN; } return; }
+    double res[2];
+    for (int which = 0; which < 2; ++which) {
+        const double q = (which == 0 ? 0.5 : 99.5) / 100.0;
+        const double virt = ((double)n * q + (1.0 + q * (1.0 - 1.0 - 1.0))) - 1.0;   // numpy _compute_virtual_index
+        const double prev = floor(virt);
+        long ip = (long)prev; if (ip < 0) ip = 0; if (ip > n - 1) ip = n - 1;
+        long in = ip + 1; if (in > n - 1) in = n - 1;
+        const double g = virt - prev;
+        const unsigned long long ka = qd_radix_select(z, n, ip, hist, &sh_prefix, &sh_t);
+        unsigned long long kb = ka;
+        if (in != ip) {
+            // rank ip+1: equal to ka if enough values <= ka, else the smallest key > ka
+            long cnt_le = 0; unsigned long long mn = ~0ull;
+            for (long i = threadIdx.x; i < n; i += blockDim.x) {
+                const unsigned long long k = qd_key(z[i]);
+                cnt_le += k <= ka;
+                if (k > ka && k < mn) mn = k;
+            }
+            // block reductions (sum of cnt_le, min of mn)
+            for (int o = 32; o > 0; o >>= 1) {
+                cnt_le += __shfl_xor((long long)cnt_le, o, 64);
+                const unsigned long long other = (unsigned long long)__shfl_xor((long long)mn, o, 64);
+                mn = other < mn ? other : mn;
+            }
+            __syncthreads();
+            if ((threadIdx.x & 63) == 0) sh_red[threadIdx.x >> 6] = (unsigned long long)cnt_le;
+            __syncthreads();
+            long tot = 0;
+            for (int w = 0; w < QD_PCT_BLOCK / 64; ++w) tot += (long)sh_red[w];
+            __syncthreads();
+            if ((threadIdx.x & 63) == 0) sh_red[threadIdx.x >> 6] = mn;
+            __syncthreads();
+            unsigned long long gm = ~0ull;
+            for (int w = 0; w < QD_PCT_BLOCK / 64; ++w) gm = sh_red[w] < gm ? sh_red[w] : gm;
+            __syncthreads();
+            kb = (tot > in) ? ka : gm;
+        }
+        res[which] = qd_lerp(qd_unkey(ka), qd_unkey(kb), g);
+    }
+    if (threadIdx.x == 0) { plohi[2 * e] = res[0]; plohi[2 * e + 1] = res[1]; }
+}
+
+// ---------------------------------------------------------------------------
+// a17 + a22: normalise and write every observation tensor.
+// grid = (ceil(P/256), n_env); thread = one (y,x).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float qd_norm(double z, double lo, double hi) {
+    if (!(hi > lo)) return 0.0f;
+    double v = (z - lo) / (hi - lo);
+    v = fmin(fmax(v, 0.0), 1.0);
+    return (float)v;
+}
+
+template <int N>
+__global__ void qd_k_write_obs(const int* __restrict__ env_ids, int R, const double* __restrict__ params,
+                               const double* __restrict__ state, const double* __restrict__ zraw,
+                               const double* __restrict__ plohi, float* __restrict__ gimg,
+                               float* __restrict__ pimg, float* __restrict__ bimg, float* __restrict__ volt) {
+    constexpr int C = N - 1, NA = 2 * N - 1;
+    const QdLayout L = qd_layout(N);
+    const int e = env_ids ? env_ids[blockIdx.y] : blockIdx.y;
+    const int P = R * R;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    const double lo = plohi[2 * e], hi = plohi[2 * e + 1];
+    if (blockIdx.x == 0 && threadIdx.x < NA && volt) {
+        const double* par = params + (size_t)e * L.size;
+        const double* st = state + (size_t)e * L.s_size;
+        const int i = threadIdx.x;
+        double v, vlo, vhi;
+        if (i < N) { v = st[L.s_gate_v + i]; vlo = par[L.pmin + i]; vhi = par[L.pmax + i]; }
+        else { v = st[L.s_barrier_v + i - N]; vlo = par[L.bmin + i - N]; vhi = par[L.bmax + i - N]; }
+        const float v32 = (float)v;                               // env.py:512 astype(float32) first
+        double t = ((double)v32 - vlo) / (vhi - vlo);
+        t = t * 2 - 1;
+        volt[(size_t)e * NA + i] = (float)t;
+    }
+    if (p >= P) return;
+    const int y = p / R, x = p - y * R;
+    const int pt = x * R + y;                                     // transposed pixel
+    const double* ze = zraw + (size_t)e * C * P;
+    float v[C], vt[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) { v[c] = qd_norm(ze[(size_t)c * P + p], lo, hi); vt[c] = qd_norm(ze[(size_t)c * P + pt], lo, hi); }
+    if (gimg) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) gimg[((size_t)e * P + p) * C + c] = v[c];
+    }
+    if (bimg) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) bimg[((size_t)e * C + c) * P + p] = v[c];
+    }
+    if (pimg) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            float a0, a1;
+            if (i == 0) { a0 = v[0]; a1 = v[0]; }
+            else if (i == N - 1) { a0 = vt[C - 1]; a1 = vt[C - 1]; }
+            else { a0 = v[i - 1]; a1 = vt[i]; }
+            float2 o; o.x = a0; o.y = a1;
+            reinterpret_cast<float2*>(pimg)[((size_t)e * N + i) * P + p] = o;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// a19 + a20 + a21: one thread per env.
+// ---------------------------------------------------------------------------
+struct QdKalmanCfg { double variance_threshold, process_noise; };
+
+// pseudo-inverse of an n x n matrix (row-major, n <= 9) by one-sided Jacobi SVD,
+// numpy.linalg.pinv semantics: singular values <= 1e-15 * s_max are dropped.
+__device__ void qd_pinv(const double* M, int n, double* Pinv) {
+    double Um[81], Vm[81], sv[9];
+    for (int i = 0; i < n * n; ++i) { Um[i] = M[i]; Vm[i] = 0.0; }
+    for (int i = 0; i < n; ++i) Vm[i * n + i] = 1.0;
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        double offmax = 0.0;
+        for (int p = 0; p < n - 1; ++p)
+            for (int q = p + 1; q < n; ++q) {
+                double app = 0, aqq = 0, apq = 0;
+                for (int k = 0; k < n; ++k) { const double up = Um[k * n + p], uq = Um[k * n + q]; app += up * up; aqq += uq * uq; apq += up * uq; }
+                if (apq == 0.0) continue;
+                const double rel = fabs(apq) / sqrt(app * aqq);
+                if (rel > offmax) offmax = rel;
+                if (!(rel > 1e-16)) continue;
+                const double zeta = (aqq - app) / (2.0 * apq);
+                const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                const double cs = 1.0 / sqrt(1.0 + t * t), sn = cs * t;
+                for (int k = 0; k < n; ++k) {
+                    const double up = Um[k * n + p], uq = Um[k * n + q];
+                    Um[k * n + p] = cs * up - sn * uq; Um[k * n + q] = sn * up + cs * uq;
+                    const double vp = Vm[k * n + p], vq = Vm[k * n + q];
+                    Vm[k * n + p] = cs * vp - sn * vq; Vm[k * n + q] = sn * vp + cs * vq;
+                }
+            }
+        if (!(offmax > 1e-15)) break;
+    }
+    double smax = 0.0;
+    for (int j = 0; j < n; ++j) {
+        double s = 0.0;
+        for (int k = 0; k < n; ++k) s += Um[k * n + j] * Um[k * n + j];
+        sv[j] = sqrt(s);
+        if (sv[j] > smax) smax = sv[j];
+    }
+    const double cutoff = 1e-15 * smax;
+    // M = U S V^T with U = Um / sv  =>  pinv = V S^-1 U^T = sum_j V[:,j] Um[:,j]^T / sv_j^2
+    for (int i = 0; i < n; ++i)
+        for (int k = 0; k < n; ++k) {
+            double acc = 0.0;
+            for (int j = 0; j < n; ++j)
+                if (sv[j] > cutoff) acc += Vm[i * n + j] * Um[k * n + j] / (sv[j] * sv[j]);
+            Pinv[i * n + k] = acc;
+        }
+}
+
+// solve A x = b (n <= 9), Gaussian elimination with partial pivoting
+__device__ void qd_solve(const double* A, const double* b, int n, double* x) {
+    double M[81], r[9];
+    for (int i = 0; i < n * n; ++i) M[i] = A[i];
+    for (int i = 0; i < n; ++i) r[i] = b[i];
+    for (int c = 0; c < n; ++c) {
+        int piv = c; double best = fabs(M[c * n + c]);
+        for (int i = c + 1; i < n; ++i) if (fabs(M[i * n + c]) > best) { best = fabs(M[i * n + c]); piv = i; }
+        if (piv != c) {
+            for (int k = 0; k < n; ++k) { const double t = M[c * n + k]; M[c * n + k] = M[piv * n + k]; M[piv * n + k] = t; }
+            const double t = r[c]; r[c] = r[piv]; r[piv] = t;
+        }
+        const double d = M[c * n + c];
+        for (int i = c + 1; i < n; ++i) {
+            const double f = M[i * n + c] / d;
+            for (int k = c; k < n; ++k) M[i * n + k] -= f * M[c * n + k];
+            r[i] -= f * r[c];
+        }
+    }
+    for (int i = n - 1; i >= 0; --i) {
+        double s = r[i];
+        for (int k = i + 1; k < n; ++k) s -= M[i * n + k] * x[k];
+        x[i] = s / M[i * n + i];
+    }
+}
+
+template <int N>
+__device__ bool qd_kalman_update(double* mean, double* var, int i, int j, double delta, double R, QdKalmanCfg kc) {
+    const int r = i < j ? i : j, c = i < j ? j : i;
+    if (R > kc.variance_threshold) return false;
+    const double Pn = var[r * N + c] + kc.process_noise;
+    const double x = mean[r * N + c];
+    const double K = Pn / (Pn + R);
+    double nm = x + K * delta;
+    const double nv = (1 - K) * Pn;
+    nm = fmin(fmax(nm, -1.0), 1.0);
+    mean[r * N + c] = nm; mean[c * N + r] = nm;
+    var[r * N + c] = nv; var[c * N + r] = nv;
+    return true;
+}
+
+template <int N>
+__global__ void qd_k_update(const int* __restrict__ env_ids, int n_env, const double* __restrict__ params,
+                            double* __restrict__ state, const float* __restrict__ values,
+                            const float* __restrict__ log_vars, int recompute_gt, QdKalmanCfg kc) {
+    constexpr int G = N + 1, C = N - 1;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_env) return;
+    const int e = env_ids ? env_ids[t] : t;
+    const QdLayout L = qd_layout(N);
+    const double* par = params + (size_t)e * L.size;
+    double* st = state + (size_t)e * L.s_size;
+    double* mean = st + L.s_kmean;
+    double* var = st + L.s_kvar;
+    if (values && log_vars) {
+        for (int i = 0; i < C; ++i) {
+            const float* vv = values + ((size_t)e * C + i) * 3;
+            const float* lv = log_vars + ((size_t)e * C + i) * 3;
+            // env.py:610-618: predictions negated; KalmanUpdater.py:87-90 clamp then exp
+            double Rv[3], dl[3];
+            for (int k = 0; k < 3; ++k) {
+                dl[k] = -(double)vv[k];
+                const double c = fmin(fmax((double)lv[k], -6.0), 2.0);
+                Rv[k] = exp(c);
+            }
+            qd_kalman_update<N>(mean, var, i, i + 1, dl[0], Rv[0], kc);
+            if (i + 2 < N) qd_kalman_update<N>(mean, var, i, i + 2, dl[1], Rv[1], kc);
+            if (i - 1 >= 0) qd_kalman_update<N>(mean, var, i + 1, i - 1, dl[2], Rv[2], kc);
+        }
+        // a20: VGM = pinv(cdd_inv_full @ (-E)), E = [[cgd_est, 0], [0, 1]]  (electrons sign folded in)
+        double M[G * G], Pv[G * G];
+        for (int i = 0; i < G; ++i)
+            for (int j = 0; j < G; ++j) {
+                double acc = 0.0;
+                for (int k = 0; k < G; ++k) {
+                    double ekj;
+                    if (k < N && j < N) ekj = (k == j) ? 1.0 : mean[k * N + j];
+                    else ekj = (k == N && j == N) ? 1.0 : 0.0;
+                    acc += par[L.cdd_inv + i * G + k] * (-ekj);
+                }
+                M[i * G + j] = acc;
+            }
+        qd_pinv(M, G, Pv);
+        for (int i = 0; i < G * G; ++i) st[L.s_vgm + i] = Pv[i];
+    }
+    if (recompute_gt) {
+        // a21: virtual = inv(VGM) (vopt - origin)
+        double rhs[G], virt[G];
+        for (int i = 0; i < G; ++i) rhs[i] = par[L.vopt + i] - par[L.origin + i];
+        qd_solve(st + L.s_vgm, rhs, G, virt);
+        for (int i = 0; i < N; ++i) st[L.s_gate_gt + i] = (double)(float)virt[i];
+        for (int b = 0; b < C; ++b) st[L.s_barrier_gt + b] = (double)(float)par[L.vbopt + b];
+        st[L.s_sensor_gt] = virt[N];
+    }
+}
+
+#endif  // __HIPCC__

@@ -200,18 +200,19 @@ struct QdLevel {
 #undef QD_CSWAP
         const bool no_minus = !(S.fl[L] > 0.0);            // delta = -1 would give c < 0
         const unsigned sh = 2u * (unsigned)(N - 1 - L);
-#define QD_VISIT(r)                                                                \
-        {                                                                          \
-            if (!(k##r == 0 && no_minus)) {                                        \
-                double pn = fma(t##r, t##r, partial);                              \
-                if (pn > S.lim) return;                                            \
-                S.d[L] = dk##r;                                                    \
-                S.idx = (S.idx & ~(3u << sh)) | ((unsigned)k##r << sh);            \
-                QdLevel<N, L + 1>::run(S, pn);                                     \
-            }                                                                      \
+        // ONE call site per level (a 4x unrolled visit would inline 4^N leaves)
+#pragma unroll 1
+        for (int r = 0; r < 4; ++r) {
+            const double tr = r == 0 ? t0 : r == 1 ? t1 : r == 2 ? t2 : t3;
+            const double dr = r == 0 ? dk0 : r == 1 ? dk1 : r == 2 ? dk2 : dk3;
+            const int kr = r == 0 ? k0 : r == 1 ? k1 : r == 2 ? k2 : k3;
+            if (kr == 0 && no_minus) continue;
+            const double pn = fma(tr, tr, partial);
+            if (pn > S.lim) return;                          // choices are in increasing |t|
+            S.d[L] = dr;
+            S.idx = (S.idx & ~(3u << sh)) | ((unsigned)kr << sh);
+            QdLevel<N, L + 1>::run(S, pn);
         }
-        QD_VISIT(0) QD_VISIT(1) QD_VISIT(2) QD_VISIT(3)
-#undef QD_VISIT
     }
 };
 

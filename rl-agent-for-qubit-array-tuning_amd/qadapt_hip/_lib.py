@@ -1,0 +1,89 @@
+"""ctypes binding of libqdsim.so (include/qdsim.h).  There is NO fallback: if the
+library is missing or a call fails, an exception is raised."""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(os.path.dirname(_HERE), "csrc")
+LIB_PATH = os.path.join(CSRC, "libqdsim.so")
+
+QD_FLAG_VALIDATE = 1
+
+EXPORTS = [
+    "qd_param_block_doubles", "qd_state_block_doubles", "qd_layout_query", "qd_create", "qd_destroy",
+    "qd_last_error", "qd_bind_outputs", "qd_load_episodes", "qd_apply_actions", "qd_observe",
+    "qd_update_capacitance", "qd_step", "qd_get_state", "qd_set_state", "qd_get_raw",
+    "qd_get_occupations", "qd_get_candidates", "qd_time_ground_kernel",
+]
+
+
+class QdConfig(ctypes.Structure):
+    _fields_ = [
+        ("struct_size", ctypes.c_int32), ("n_dot", ctypes.c_int32), ("resolution", ctypes.c_int32),
+        ("batch", ctypes.c_int32), ("max_steps", ctypes.c_int32), ("env_chunk", ctypes.c_int32),
+        ("flags", ctypes.c_int32), ("reserved", ctypes.c_int32),
+        ("gate_ramp_start", ctypes.c_double), ("gate_quadratic_start", ctypes.c_double),
+        ("barrier_ramp_start", ctypes.c_double), ("kalman_prior_mean", ctypes.c_double),
+        ("kalman_prior_variance", ctypes.c_double), ("kalman_prior_mean_nnn", ctypes.c_double),
+        ("kalman_variance_threshold", ctypes.c_double), ("kalman_process_noise", ctypes.c_double),
+    ]
+
+
+class QdError(RuntimeError):
+    pass
+
+
+def build(force=False):
+    """Compile libqdsim.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    if force and os.path.exists(LIB_PATH):
+        os.remove(LIB_PATH)
+    subprocess.check_call(["make", "-s", "-C", CSRC, "libqdsim.so"])
+    return LIB_PATH
+
+
+_LIB = None
+
+
+def lib():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise QdError(
+            f"{LIB_PATH} not found: build it with `make -C {CSRC}` (or __graft_entry__.build()). "
+            "qadapt_hip has no CPU fallback.")
+    L = ctypes.CDLL(LIB_PATH)
+    vp, ip, fp, dp = ctypes.c_void_p, ctypes.POINTER(ctypes.c_int32), ctypes.c_void_p, ctypes.c_void_p
+    L.qd_param_block_doubles.argtypes = [ctypes.c_int]; L.qd_param_block_doubles.restype = ctypes.c_int
+    L.qd_state_block_doubles.argtypes = [ctypes.c_int]; L.qd_state_block_doubles.restype = ctypes.c_int
+    L.qd_layout_query.argtypes = [ctypes.c_int, ip]; L.qd_layout_query.restype = ctypes.c_int
+    L.qd_create.argtypes = [ctypes.POINTER(QdConfig), ctypes.c_int, ctypes.POINTER(vp)]
+    L.qd_create.restype = ctypes.c_int
+    L.qd_destroy.argtypes = [vp]; L.qd_destroy.restype = ctypes.c_int
+    L.qd_last_error.argtypes = [vp]; L.qd_last_error.restype = ctypes.c_char_p
+    L.qd_bind_outputs.argtypes = [vp, fp, fp, fp, fp]; L.qd_bind_outputs.restype = ctypes.c_int
+    L.qd_load_episodes.argtypes = [vp, ip, ctypes.c_int, dp, dp, ctypes.c_int, vp]
+    L.qd_load_episodes.restype = ctypes.c_int
+    L.qd_apply_actions.argtypes = [vp, fp, dp, vp, vp]; L.qd_apply_actions.restype = ctypes.c_int
+    L.qd_observe.argtypes = [vp, vp, ctypes.c_int, vp]; L.qd_observe.restype = ctypes.c_int
+    L.qd_update_capacitance.argtypes = [vp, vp, ctypes.c_int, fp, fp, ctypes.c_int, vp]
+    L.qd_update_capacitance.restype = ctypes.c_int
+    L.qd_step.argtypes = [vp, fp, fp, fp, dp, vp, vp]; L.qd_step.restype = ctypes.c_int
+    L.qd_get_state.argtypes = [vp, dp, vp]; L.qd_get_state.restype = ctypes.c_int
+    L.qd_set_state.argtypes = [vp, dp, vp]; L.qd_set_state.restype = ctypes.c_int
+    L.qd_get_raw.argtypes = [vp, dp, dp]; L.qd_get_raw.restype = ctypes.c_int
+    L.qd_get_occupations.argtypes = [vp, dp]; L.qd_get_occupations.restype = ctypes.c_int
+    L.qd_get_candidates.argtypes = [vp, vp]; L.qd_get_candidates.restype = ctypes.c_int
+    L.qd_time_ground_kernel.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_float), vp]
+    L.qd_time_ground_kernel.restype = ctypes.c_int
+    _LIB = L
+    return L
+
+
+def check(handle, rc, what):
+    if rc != 0:
+        msg = lib().qd_last_error(handle).decode() if handle else "no handle"
+        raise QdError(f"{what} failed (code {rc}): {msg}")

@@ -1,0 +1,278 @@
+"""
+VecQuantumDeviceEnv -- B quantum-dot tuning environments stepped as one batch on
+one MI355X.  Host side of the C-ABI in include/qdsim.h; observation / action
+buffers are PyTorch-ROCm tensors, the computation is the HIP library.
+
+Semantics per env are those of the reference's QuantumDeviceEnv
+(src/qadapt/environment/env.py:135-315): reset() builds a new random device,
+identity VGM, ground truth, voltage ranges, random start, first observation and
+a Kalman/VGM update; step() rescales the action, pays the reward against the
+PREVIOUS ground truth, renders the N-1 CSD channels, normalises them, updates
+Kalman/VGM and then the ground truth.  The capacitance CNN (env.py:568-581) is
+an input provider here: pass `capacitance_model=callable`, or
+`update_method: null` in the env config, or per-step `cnn_outputs`.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from .device_model import DeviceSampler, load_yaml
+from .layout import layout
+
+
+class _DevPtr:
+    """Zero-copy torch view over library-owned device memory."""
+
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr,
+                                         "data": (int(ptr), False), "version": 2}
+
+
+class SyntheticCapacitanceModel:
+    """Stand-in for the capacitance CNN used by benchmarks and tests
+    (values ~ N(0, 0.1^2), log_vars ~ U(-6, -2)); deterministic
+    per (seed, call index)."""
+
+    def __init__(self, seed=99):
+        self.seed = seed
+        self.calls = 0
+
+    def __call__(self, images):
+        n = images.shape[0]
+        g = torch.Generator(device="cpu").manual_seed(self.seed + self.calls)
+        self.calls += 1
+        values = torch.randn((n, 3), generator=g, dtype=torch.float32) * 0.1
+        log_vars = torch.rand((n, 3), generator=g, dtype=torch.float32) * 4.0 - 6.0
+        return values.to(images.device), log_vars.to(images.device)
+
+
+class VecQuantumDeviceEnv:
+    def __init__(self, num_envs, num_dots=None, config_path=None, qarray_config_path=None,
+                 resolution=None, device=None, seed=1234, env_id_offset=0, capacitance_model=None,
+                 validate=False, env_chunk=0, reset_kalman_on_reset=False):
+        self.config = load_yaml(config_path, "env_config.yaml")
+        self.qconfig = load_yaml(qarray_config_path, "qarray_config.yaml")
+        sim = self.config["simulator"]
+        self.num_envs = int(num_envs)
+        self.num_dots = int(num_dots if num_dots is not None else sim["num_dots"])
+        self.use_barriers = bool(sim["use_barriers"])
+        if not self.use_barriers:
+            raise NotImplementedError("env.py only supports barrier mode for now")      # env.py:61-62
+        if sim.get("use_deltas"):
+            raise NotImplementedError("use_deltas=true is not built (reference default is false)")
+        if self.config["reward"].get("sparse_reward") or self.config["reward"].get("gate_curve_type") != "constant":
+            raise NotImplementedError("only the default dense reward with gate_curve_type 'constant' is built")
+        self.resolution = int(resolution if resolution is not None else sim["resolution"])
+        self.max_steps = int(sim["max_steps"])
+        self.update_method = self.config["capacitance_model"]["update_method"]
+        if self.update_method not in (None, "kalman"):
+            raise NotImplementedError(f"update_method {self.update_method!r}: only null and 'kalman' are built")
+        if self.config["capacitance_model"].get("nearest_neighbour"):
+            raise NotImplementedError("nearest_neighbour (2-output) capacitance mode is not built")
+        self.capacitance_model = capacitance_model
+        if self.update_method == "kalman" and capacitance_model is None:
+            # same exception type as env.py:801-802
+            raise RuntimeError("Error initialising capacitance model: update_method 'kalman' needs a "
+                               "capacitance_model callable (images -> values, log_vars)")
+        if not torch.cuda.is_available():
+            raise RuntimeError("VecQuantumDeviceEnv needs a ROCm GPU (no CPU fallback)")
+        self.device = torch.device(device if device is not None else "cuda:0")
+        self.reset_kalman_on_reset = bool(reset_kalman_on_reset)
+        N = self.num_dots; R = self.resolution; B = self.num_envs
+        self.N, self.R, self.B, self.C = N, R, B, N - 1
+        self.L = layout(N)
+        self.sampler = DeviceSampler(N, self.qconfig, self.config)
+        self._rngs = [np.random.Generator(np.random.PCG64(seed + env_id_offset + e)) for e in range(B)]
+        # ---- library handle ---------------------------------------------------
+        self._lib = _lib.lib()
+        rew = self.config["reward"]; cm = self.config["capacitance_model"]
+        cfg = _lib.QdConfig(struct_size=ctypes.sizeof(_lib.QdConfig), n_dot=N, resolution=R, batch=B,
+                            max_steps=self.max_steps, env_chunk=int(env_chunk),
+                            flags=_lib.QD_FLAG_VALIDATE if validate else 0, reserved=0,
+                            gate_ramp_start=float(rew["gate_ramp_start"]),
+                            gate_quadratic_start=float(rew["gate_quadratic_start"]),
+                            barrier_ramp_start=float(rew["barrier_ramp_start"]),
+                            kalman_prior_mean=0.3, kalman_prior_variance=0.5, kalman_prior_mean_nnn=0.15,
+                            kalman_variance_threshold=float(cm.get("variance_threshold", 0.05)),
+                            kalman_process_noise=float(cm.get("process_noise", 0.0)))
+        self._h = ctypes.c_void_p()
+        rc = self._lib.qd_create(ctypes.byref(cfg), self.device.index or 0, ctypes.byref(self._h))
+        _lib.check(self._h, rc, "qd_create")
+        self.validate = bool(validate)
+        # ---- caller-owned output tensors ---------------------------------------
+        dev = self.device
+        self.global_image = torch.zeros((B, R, R, self.C), dtype=torch.float32, device=dev)
+        self.plunger_images = torch.zeros((B, N, R, R, 2), dtype=torch.float32, device=dev)
+        self.barrier_images = torch.zeros((B, self.C, R, R, 1), dtype=torch.float32, device=dev)
+        self.voltages = torch.zeros((B, 2 * N - 1), dtype=torch.float32, device=dev)
+        self.rewards = torch.zeros((B, 2 * N - 1), dtype=torch.float64, device=dev)
+        self.truncated = torch.zeros((B,), dtype=torch.uint8, device=dev)
+        _lib.check(self._h, self._lib.qd_bind_outputs(self._h, self.global_image.data_ptr(),
+                                                      self.plunger_images.data_ptr(),
+                                                      self.barrier_images.data_ptr(),
+                                                      self.voltages.data_ptr()), "qd_bind_outputs")
+        self._params_host = np.zeros((B, self.L.size))
+        self._needs_reset = True
+
+    # ------------------------------------------------------------------ helpers
+    def _stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.qd_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _obs(self):
+        N = self.N
+        return {"image": self.global_image, "obs_gate_voltages": self.voltages[:, :N],
+                "obs_barrier_voltages": self.voltages[:, N:], "plunger_images": self.plunger_images,
+                "barrier_images": self.barrier_images}
+
+    def _cnn(self, env_ids=None):
+        """Run the capacitance model on the current images of `env_ids` (all if None);
+        returns full-batch (B,C,3) tensors as qd_update_capacitance expects."""
+        if self.capacitance_model is None:
+            return None, None
+        img = self.barrier_images if env_ids is None else self.barrier_images[env_ids]
+        n = img.shape[0]
+        batch = img.reshape(n * self.C, 1, self.R, self.R)          # (C,1,R,R) per env, env.py:568-574
+        values, log_vars = self.capacitance_model(batch)
+        values = values.to(torch.float32).reshape(n, self.C, 3)
+        log_vars = log_vars.to(torch.float32).reshape(n, self.C, 3)
+        if env_ids is None:
+            return values.contiguous(), log_vars.contiguous()
+        fv = torch.zeros((self.B, self.C, 3), dtype=torch.float32, device=self.device)
+        fl = torch.zeros_like(fv)
+        fv[env_ids] = values; fl[env_ids] = log_vars
+        return fv, fl
+
+    # ------------------------------------------------------------------ reset
+    def reset(self, env_ids=None, seed=None, options=None, cnn_outputs=None):
+        """Reset the listed envs (all if None).  Returns the observation dict of
+        the whole batch (device tensors, valid until the next call)."""
+        ids = np.arange(self.B, dtype=np.int32) if env_ids is None else np.asarray(env_ids, dtype=np.int32).reshape(-1)
+        if ids.size == 0:
+            return self._obs()
+        if seed is not None:
+            for e in ids:
+                self._rngs[e] = np.random.Generator(np.random.PCG64(int(seed) + int(e)))
+        u = np.stack([self._rngs[e].random(self.sampler.n_draws) for e in ids])
+        eb = self.sampler.build(u)
+        self._params_host[ids] = eb.params
+        self.last_episode = eb
+        ip = ids.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))
+        rc = self._lib.qd_load_episodes(self._h, ip, int(ids.size), eb.params.ctypes.data, eb.state.ctypes.data,
+                                        1 if self.reset_kalman_on_reset else 0, self._stream())
+        _lib.check(self._h, rc, "qd_load_episodes")
+        all_envs = ids.size == self.B and np.array_equal(ids, np.arange(self.B))
+        ids_dev = None if all_envs else torch.as_tensor(ids, dtype=torch.int32, device=self.device)
+        idp = None if all_envs else ctypes.c_void_p(ids_dev.data_ptr())
+        _lib.check(self._h, self._lib.qd_observe(self._h, idp, int(ids.size), self._stream()), "qd_observe")
+        if cnn_outputs is not None:
+            values, log_vars = cnn_outputs
+        else:
+            values, log_vars = self._cnn(None if all_envs else ids_dev.long())
+        if values is not None:
+            values = values.contiguous(); log_vars = log_vars.contiguous()
+            rc = self._lib.qd_update_capacitance(self._h, idp, int(ids.size), values.data_ptr(), log_vars.data_ptr(),
+                                                 0, self._stream())             # reset does not refresh the ground truth (env.py:233)
+            _lib.check(self._h, rc, "qd_update_capacitance")
+            self._keep = (values, log_vars, ids_dev)
+        self._needs_reset = False
+        return self._obs()
+
+    # ------------------------------------------------------------------ step
+    def step(self, actions, cnn_outputs=None, auto_reset=False):
+        """actions: (B, 2N-1) float32 tensor (gates then barriers) or the reference's
+        dict {"action_gate_voltages": (B,N), "action_barrier_voltages": (B,N-1)}.
+        Returns (obs, rewards (B,2N-1) float64, terminated (B) bool, truncated (B) bool)."""
+        if self._needs_reset:
+            raise RuntimeError("step() called before reset()")
+        if isinstance(actions, dict):
+            actions = torch.cat([torch.as_tensor(actions["action_gate_voltages"]),
+                                 torch.as_tensor(actions["action_barrier_voltages"])], dim=-1)
+        actions = torch.as_tensor(actions, dtype=torch.float32, device=self.device).reshape(self.B, 2 * self.N - 1).contiguous()
+        st = self._stream()
+        if cnn_outputs is not None:
+            values, log_vars = (t.to(torch.float32).contiguous() for t in cnn_outputs)
+            rc = self._lib.qd_step(self._h, actions.data_ptr(), values.data_ptr(), log_vars.data_ptr(),
+                                   self.rewards.data_ptr(), self.truncated.data_ptr(), st)
+            _lib.check(self._h, rc, "qd_step")
+            self._keep = (actions, values, log_vars)
+        else:
+            _lib.check(self._h, self._lib.qd_apply_actions(self._h, actions.data_ptr(), self.rewards.data_ptr(),
+                                                           self.truncated.data_ptr(), st), "qd_apply_actions")
+            _lib.check(self._h, self._lib.qd_observe(self._h, None, 0, st), "qd_observe")
+            values, log_vars = self._cnn(None)
+            vp = values.data_ptr() if values is not None else None
+            lp = log_vars.data_ptr() if log_vars is not None else None
+            _lib.check(self._h, self._lib.qd_update_capacitance(self._h, None, 0, vp, lp, 1, st),
+                       "qd_update_capacitance")
+            self._keep = (actions, values, log_vars)
+        truncated = self.truncated.bool()
+        terminated = torch.zeros_like(truncated)
+        obs = self._obs()
+        if auto_reset:
+            done = torch.nonzero(truncated).reshape(-1)
+            if done.numel():
+                obs = self.reset(env_ids=done.cpu().numpy())
+        return obs, self.rewards, terminated, truncated
+
+    # ------------------------------------------------------------------ state access
+    def get_state(self):
+        """Host copy of the per-env state blocks and step counters (checkpointing,
+        infos, validation)."""
+        st = np.zeros((self.B, self.L.s_size)); steps = np.zeros(self.B, np.int32)
+        _lib.check(self._h, self._lib.qd_get_state(self._h, st.ctypes.data, steps.ctypes.data), "qd_get_state")
+        return st, steps
+
+    def set_state(self, state, steps):
+        state = np.ascontiguousarray(state, dtype=np.float64); steps = np.ascontiguousarray(steps, dtype=np.int32)
+        _lib.check(self._h, self._lib.qd_set_state(self._h, state.ctypes.data, steps.ctypes.data), "qd_set_state")
+
+    def device_state(self):
+        """The reference's info["current_device_state"] for every env (env.py:214-222)."""
+        st, steps = self.get_state()
+        L, N, G = self.L, self.N, self.N + 1
+        return {"gate_ground_truth": st[:, L.s_gate_gt:L.s_gate_gt + N].astype(np.float32),
+                "barrier_ground_truth": st[:, L.s_barrier_gt:L.s_barrier_gt + N - 1].astype(np.float32),
+                "sensor_ground_truth": st[:, L.s_sensor_gt].copy(),
+                "current_gate_voltages": st[:, L.s_gate_v:L.s_gate_v + N].copy(),
+                "current_barrier_voltages": st[:, L.s_barrier_v:L.s_barrier_v + N - 1].copy(),
+                "virtual_gate_matrix": st[:, L.s_vgm:L.s_vgm + G * G].reshape(-1, G, G).copy(),
+                "virtual_gate_origin": self._params_host[:, L.origin:L.origin + G].copy(),
+                "kalman_means": st[:, L.s_kmean:L.s_kmean + N * N].reshape(-1, N, N).copy(),
+                "kalman_variances": st[:, L.s_kvar:L.s_kvar + N * N].reshape(-1, N, N).copy(),
+                "steps": steps}
+
+    def raw(self):
+        raw = np.zeros((self.B, self.C, self.R * self.R)); pl = np.zeros((self.B, 2))
+        _lib.check(self._h, self._lib.qd_get_raw(self._h, raw.ctypes.data, pl.ctypes.data), "qd_get_raw")
+        return raw, pl
+
+    def occupations(self):
+        occ = np.zeros((self.B, self.C, self.R * self.R, self.N))
+        _lib.check(self._h, self._lib.qd_get_occupations(self._h, occ.ctypes.data), "qd_get_occupations")
+        return occ
+
+    def candidates(self):
+        st = np.zeros((self.B, self.C, self.R * self.R, 32, self.N), np.int32)
+        _lib.check(self._h, self._lib.qd_get_candidates(self._h, st.ctypes.data), "qd_get_candidates")
+        return st
+
+    def time_ground_kernel(self, iters=3):
+        ms = ctypes.c_float(0)
+        _lib.check(self._h, self._lib.qd_time_ground_kernel(self._h, iters, ctypes.byref(ms), self._stream()),
+                   "qd_time_ground_kernel")
+        return float(ms.value)

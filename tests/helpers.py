@@ -1,0 +1,118 @@
+"""Shared test helpers: scenes built with the PRODUCT's host-side sampler and
+thin views that let the oracle consume exactly the same numbers."""
+import ctypes
+import os
+import subprocess
+import types
+
+import numpy as np
+
+import qd_oracle as O
+from qadapt_hip import device_model as DM
+from qadapt_hip.layout import layout, LAYOUT_FIELDS
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "rl-agent-for-qubit-array-tuning_amd", "csrc")
+
+
+def configs(resolution=None, radial=False):
+    q = DM.load_yaml(None, "qarray_config.yaml")
+    e = DM.load_yaml(None, "env_config.yaml")
+    if resolution is not None:
+        e["simulator"]["resolution"] = resolution
+    e["simulator"]["radial_noise"]["enabled"] = bool(radial) or e["simulator"]["radial_noise"]["enabled"]
+    return q, e
+
+
+def sample_blocks(N, seeds):
+    q, e = configs()
+    s = DM.DeviceSampler(N, q, e)
+    u = np.stack([np.random.default_rng(int(sd)).random(s.n_draws) for sd in seeds])
+    return s.build(u)
+
+
+def dev_view(N, par):
+    """Oracle `Device`-like view over a product parameter block."""
+    L = layout(N); G = N + 1; nb = N - 1
+    d = types.SimpleNamespace()
+    d.n_dot = N; d.n_gate = G; d.n_barrier = nb
+    d.cdd_inv_full = par[L.cdd_inv:L.cdd_inv + G * G].reshape(G, G).copy()
+    d.cgd_full = par[L.cgd:L.cgd + G * 2 * N].reshape(G, 2 * N).copy()
+    d.Cbg = par[L.cbg:L.cbg + nb * G].reshape(nb, G).copy()
+    d.Cbb = np.eye(nb)
+    d.alpha = par[L.alpha:L.alpha + nb].copy()
+    d.tc_base = float(par[L.scal]); d.gamma = float(par[L.scal + 1])
+    d.optimal_tc = 1e-3
+    d.n_star = np.array([1.0] * N + [0.53])
+    d.window = float(par[L.scal + 2])
+    d.origin = par[L.origin:L.origin + G].copy()
+    return d
+
+
+def state_view(N, st):
+    L = layout(N); G = N + 1; nb = N - 1
+    return types.SimpleNamespace(
+        vgm=st[L.s_vgm:L.s_vgm + G * G].reshape(G, G).copy(),
+        gate_v=st[L.s_gate_v:L.s_gate_v + N].copy(),
+        barrier_v=st[L.s_barrier_v:L.s_barrier_v + nb].copy(),
+        gate_gt=st[L.s_gate_gt:L.s_gate_gt + N].copy(),
+        barrier_gt=st[L.s_barrier_gt:L.s_barrier_gt + nb].copy(),
+        sensor_gt=float(st[L.s_sensor_gt]))
+
+
+def place(N, st, mode, rng, vgm_noise=0.05):
+    """Move the env's voltages near/mid/far from its ground truth and perturb the VGM."""
+    L = layout(N); G = N + 1; nb = N - 1
+    span = {"near": (3, 3), "mid": (10, 6), "far": (40, 12), "start": None}[mode]
+    st = st.copy()
+    if span is not None:
+        st[L.s_gate_v:L.s_gate_v + N] = st[L.s_gate_gt:L.s_gate_gt + N] + rng.uniform(-span[0], span[0], N)
+        st[L.s_barrier_v:L.s_barrier_v + nb] = st[L.s_barrier_gt:L.s_barrier_gt + nb] + rng.uniform(-span[1], span[1], nb)
+    if vgm_noise:
+        st[L.s_vgm:L.s_vgm + G * G] += rng.normal(0, vgm_noise, G * G)
+    return st
+
+
+_HOST = None
+
+
+def hosttest():
+    global _HOST
+    if _HOST is None:
+        subprocess.check_call(["make", "-s", "-C", CSRC, "hosttest"])
+        _HOST = ctypes.CDLL(os.path.join(CSRC, "libqdsim_hosttest.so"))
+        _HOST.qdh_sensor.restype = ctypes.c_double
+    return _HOST
+
+
+def _p(a, t):
+    return a.ctypes.data_as(ctypes.POINTER(t))
+
+
+def host_front(N, par, st, ch, R, pix=None):
+    h = hosttest()
+    P = R * R
+    p0, p1 = (0, P) if pix is None else pix
+    par = np.ascontiguousarray(par); st = np.ascontiguousarray(st)
+    states = np.zeros((P, 32, N), np.int32); floors = np.zeros((P, N), np.int32)
+    vpp = np.zeros((P, N + 1)); tc = np.zeros((P, N - 1)); nv = np.zeros(P, np.int32)
+    stats = np.zeros(3, np.uint64)
+    rc = h.qdh_front(N, _p(par, ctypes.c_double), _p(st, ctypes.c_double), ch, R, p0, p1,
+                     _p(states, ctypes.c_int32), _p(floors, ctypes.c_int32), _p(vpp, ctypes.c_double),
+                     _p(tc, ctypes.c_double), _p(nv, ctypes.c_int32), _p(stats, ctypes.c_uint64))
+    assert rc == 0
+    return dict(states=states, floors=floors, vpp=vpp, tc=tc, nvalid=nv, stats=stats)
+
+
+def host_sensor(N, par, vpp, occ):
+    h = hosttest()
+    par = np.ascontiguousarray(par); vpp = np.ascontiguousarray(vpp); occ = np.ascontiguousarray(occ)
+    return h.qdh_sensor(N, _p(par, ctypes.c_double), _p(vpp, ctypes.c_double), _p(occ, ctypes.c_double))
+
+
+def host_layout(N):
+    h = hosttest()
+    n = h.qdh_layout_ints()
+    out = np.zeros(n, np.int32)
+    h.qdh_layout(N, _p(out, ctypes.c_int))
+    return dict(zip(LAYOUT_FIELDS, out.tolist()))

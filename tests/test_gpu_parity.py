@@ -1,0 +1,185 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through
+the C-ABI, against the oracle on the same seeded inputs.
+
+Bars (BASELINE.json north_star): integer charge states bit-exact; float CSD
+observations within 1e-6 relative (written below as rtol/atol on each check)."""
+import numpy as np
+import pytest
+
+import qd_oracle as O
+import qd_oracle_c as OC
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def _env(B, N, R, **kw):
+    import torch
+    from qadapt_hip.vec_env import VecQuantumDeviceEnv, SyntheticCapacitanceModel
+    assert torch.cuda.is_available()
+    kw.setdefault("capacitance_model", SyntheticCapacitanceModel(7))
+    return VecQuantumDeviceEnv(B, num_dots=N, resolution=R, validate=True, **kw)
+
+
+def _cnn(B, C, seed):
+    import torch
+    rng = np.random.default_rng(seed)
+    v = rng.normal(0, 0.1, (B, C, 3)).astype(np.float32)
+    lv = rng.uniform(-6, -2, (B, C, 3)).astype(np.float32)
+    return v, lv, (torch.as_tensor(v).cuda(), torch.as_tensor(lv).cuda())
+
+
+def test_library_exports_and_layout():
+    from qadapt_hip import _lib
+    from qadapt_hip.layout import layout, LAYOUT_FIELDS
+    L = _lib.lib()
+    for name in _lib.EXPORTS:
+        assert hasattr(L, name)
+    import ctypes
+    for N in range(2, 9):
+        out = (ctypes.c_int32 * 27)()
+        assert L.qd_layout_query(N, out) == 0
+        py = layout(N)
+        assert [getattr(py, f) for f in LAYOUT_FIELDS] == list(out)
+
+
+@pytest.mark.parametrize("N,R,mode", [(2, 32, "near"), (2, 16, "far"), (3, 16, "mid"), (4, 32, "near"),
+                                       (4, 16, "mid"), (6, 12, "near"), (8, 16, "near"), (8, 8, "mid")])
+def test_csd_pipeline_matches_oracle(N, R, mode):
+    B = 3
+    env = _env(B, N, R)
+    env.reset()
+    st, steps = env.get_state()
+    rng = np.random.default_rng(1000 + 10 * N + len(mode))
+    for e in range(B):
+        st[e] = H.place(N, st[e], mode if e else "near", rng)
+    env.set_state(st, steps)
+    import ctypes
+    from qadapt_hip import _lib
+    _lib.check(env._h, env._lib.qd_observe(env._h, None, 0, env._stream()), "qd_observe")
+    raw, plohi = env.raw()
+    occ = env.occupations()
+    cand = env.candidates()
+    img = env.global_image.cpu().numpy()
+    for e in range(B):
+        par = env._params_host[e]
+        dev = H.dev_view(N, par); sv = H.state_view(N, st[e])
+        ref_raw = np.zeros((N - 1, R * R))
+        for ch in range(N - 1):
+            ref = OC.csd_channel(dev, sv.vgm, dev.origin, sv.gate_v, sv.sensor_gt, sv.barrier_v, dev.window, ch, R)
+            # integer charge states: bit-exact
+            assert np.array_equal(cand[e, ch], ref["states"]), (e, ch)
+            # occupations: expectation values; compare where the spectrum is resolvable in float64
+            ok = ref["tc"].max(axis=1) < 1e6
+            assert np.allclose(occ[e, ch][ok], ref["occ"][ok], rtol=1e-6, atol=1e-6), (e, ch)
+            assert np.allclose(raw[e, ch][ok], ref["z"][ok], rtol=1e-6, atol=1e-9), (e, ch)
+            ref_raw[ch] = ref["z"]
+        # percentiles of the GPU's own raw data: exact numpy semantics
+        assert plohi[e, 0] == np.percentile(raw[e], 0.5) and plohi[e, 1] == np.percentile(raw[e], 99.5)
+        # normalised image (R,R,C) float32
+        mine = O.normalise_image(raw[e].reshape(N - 1, R, R).transpose(1, 2, 0))
+        assert np.array_equal(img[e], mine)
+        if np.all([True]):
+            full = O.normalise_image(ref_raw.reshape(N - 1, R, R).transpose(1, 2, 0))
+            resolvable = np.abs(full - img[e]) <= 2e-6
+            assert resolvable.mean() > 0.999
+    # per-agent views
+    pim = env.plunger_images.cpu().numpy(); bim = env.barrier_images.cpu().numpy()
+    for e in range(B):
+        ag = O.agent_images(img[e], N)
+        for i in range(N):
+            assert np.array_equal(pim[e, i], ag[f"plunger_{i}"])
+        for j in range(N - 1):
+            assert np.array_equal(bim[e, j], ag[f"barrier_{j}"])
+    env.close()
+
+
+@pytest.mark.parametrize("N,R", [(2, 16), (4, 16), (8, 8)])
+def test_episode_matches_oracle_env(N, R):
+    """reset + 4 steps: voltages, rewards (previous ground truth), truncation,
+    Kalman state, VGM, ground truth and images vs the oracle env."""
+    import torch
+    B, C = 2, N - 1
+    seed = 4321
+    env = _env(B, N, R, seed=seed)
+    env.max_steps = 50
+    v0, l0, t0 = _cnn(B, C, 1)
+    obs = env.reset(cnn_outputs=t0)
+    oenvs = []
+    for e in range(B):
+        oe = O.OracleEnv(N, R)
+        so = O.sample_episode(np.random.default_rng(seed + e), N)
+        oobs = oe.reset(so, v0[e], l0[e])
+        oenvs.append(oe)
+        assert np.allclose(obs["obs_gate_voltages"][e].cpu().numpy(), oobs["obs_gate_voltages"], atol=1e-6)
+        d = np.abs(obs["image"][e].cpu().numpy() - oobs["image"])
+        assert (d <= 2e-6).mean() > 0.995
+    ds = env.device_state()
+    for e, oe in enumerate(oenvs):
+        assert np.allclose(ds["kalman_means"][e], oe.kalman.means, rtol=1e-12, atol=1e-15)
+        assert np.allclose(ds["kalman_variances"][e], oe.kalman.vars, rtol=1e-12, atol=1e-15)
+        assert np.allclose(ds["virtual_gate_matrix"][e], oe.vgm, rtol=1e-9, atol=1e-11)
+        assert np.allclose(ds["gate_ground_truth"][e], oe.gate_gt, rtol=1e-6)
+    rng = np.random.default_rng(5)
+    for step in range(4):
+        act = rng.uniform(-1.2, 1.2, (B, 2 * N - 1)).astype(np.float32)
+        v, l, t = _cnn(B, C, 10 + step)
+        obs, rew, term, trunc = env.step(torch.as_tensor(act).cuda(), cnn_outputs=t)
+        ds = env.device_state()
+        for e, oe in enumerate(oenvs):
+            oobs, (gr, br), oterm, otrunc = oe.step(act[e, :N], act[e, N:], v[e], l[e])
+            assert np.allclose(ds["current_gate_voltages"][e], oe.gate_v, rtol=1e-13)
+            assert np.allclose(ds["current_barrier_voltages"][e], oe.barrier_v, rtol=1e-13)
+            r = rew[e].cpu().numpy()
+            assert np.allclose(r[:N], gr, rtol=1e-9, atol=1e-12) and np.allclose(r[N:], br, rtol=1e-9, atol=1e-12)
+            assert bool(trunc[e]) == otrunc and not bool(term[e])
+            assert np.allclose(ds["kalman_means"][e], oe.kalman.means, rtol=1e-12, atol=1e-15)
+            assert np.allclose(ds["virtual_gate_matrix"][e], oe.vgm, rtol=1e-8, atol=1e-10)
+            assert np.allclose(ds["gate_ground_truth"][e], oe.gate_gt, rtol=2e-6, atol=1e-6)
+            assert np.isclose(ds["sensor_ground_truth"][e], oe.sensor_gt, rtol=1e-8)
+            assert np.allclose(obs["obs_gate_voltages"][e].cpu().numpy(), oobs["obs_gate_voltages"], atol=1e-6)
+            assert np.allclose(obs["obs_barrier_voltages"][e].cpu().numpy(), oobs["obs_barrier_voltages"], atol=1e-6)
+            d = np.abs(obs["image"][e].cpu().numpy() - oobs["image"])
+            assert (d <= 2e-6).mean() > 0.99, (step, e, (d > 2e-6).sum())
+    env.close()
+
+
+def test_truncation_and_partial_reset():
+    import torch
+    N, R, B = 2, 8, 4
+    env = _env(B, N, R)
+    env.reset()
+    st, steps = env.get_state()
+    steps[:] = [48, 10, 49, 0]
+    env.set_state(st, steps)
+    act = torch.zeros((B, 2 * N - 1), device="cuda")
+    _, _, term, trunc = env.step(act)
+    assert trunc.cpu().tolist() == [False, False, True, False] and not term.any()
+    _, _, _, trunc = env.step(act, auto_reset=True)
+    assert trunc.cpu().tolist() == [True, False, True, False]
+    _, steps2 = env.get_state()
+    assert steps2.tolist() == [0, 12, 0, 2]
+    env.close()
+
+
+def test_classical_limit_gives_integer_argmin():
+    """tc_base = 0 => H_t = 0 => occupations are the integers of the lowest-energy
+    candidate, bit-exact (the 'integer charge occupations' of BASELINE.json)."""
+    N, R, B = 4, 16, 2
+    env = _env(B, N, R)
+    env.reset()
+    L = env.L
+    # zero the tunnel coupling of env 0 and re-upload its episode
+    import ctypes
+    eb = env.last_episode
+    eb.params[0, L.scal] = 0.0
+    ids = np.array([0], np.int32)
+    from qadapt_hip import _lib
+    _lib.check(env._h, env._lib.qd_load_episodes(env._h, ids.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), 1,
+                                                 eb.params[:1].ctypes.data, eb.state[:1].ctypes.data, 0,
+                                                 env._stream()), "load")
+    _lib.check(env._h, env._lib.qd_observe(env._h, None, 0, env._stream()), "observe")
+    occ = env.occupations(); cand = env.candidates()
+    assert np.array_equal(occ[0], np.round(occ[0]))
+    assert np.array_equal(occ[0], cand[0][:, :, 0, :].astype(float))   # rank-0 candidate = argmin
+    env.close()
