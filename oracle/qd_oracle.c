@@ -282,7 +282,7 @@ static double qd_lerp(double a, double b, double t) {
 }
 static double qd_percentile_sorted(const double *s, long n, double q_percent) {
     double q = q_percent / 100.0;
-    double virt = ((double)n * q + (1.0 + q * (1.0 - 1.0 - 1.0))) - 1.0;
+    double virt = (double)(n - 1) * q;      /* numpy 'linear' method: (n-1)*quantile */
     double prev = floor(virt);
     long ip = (long)prev; if (ip < 0) ip = 0; if (ip > n - 1) ip = n - 1;
     long in = ip + 1; if (in > n - 1) in = n - 1;

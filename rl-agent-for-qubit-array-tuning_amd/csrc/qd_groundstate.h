@@ -156,13 +156,18 @@ __device__ void qd_ground_pixel(const double* __restrict__ A, const QdPixelRec* 
     }
 
     // ---- 2. hop neighbours -------------------------------------------------
+    // pairs whose coupling is exactly zero do not link states (keeps the classical
+    // limit tc == 0 exactly diagonal, as a dense eigh of a diagonal matrix would)
+    unsigned tcnz = 0;
+#pragma unroll
+    for (int d = 0; d < N - 1; ++d) tcnz |= (rec->tc[d] != 0.0 ? 1u : 0u) << d;
     unsigned nbrmask = 0;
     for (int j = 0; j < 32; ++j) {
         const unsigned cj = __shfl(ecode, j, 32);
         const int Y = (int)cj - (int)ecode;
         const unsigned ay = (unsigned)(Y < 0 ? -Y : Y);
         const int tz = ay ? __builtin_ctz(ay) : 0;
-        const bool hop = ay != 0 && (ay >> tz) == 15u && (tz & 3) == 0;
+        const bool hop = ay != 0 && (ay >> tz) == 15u && (tz & 3) == 0 && ((tcnz >> (N - 2 - (tz >> 2))) & 1u);
         if (hop && valid && j < nvalid) nbrmask |= 1u << j;
     }
     const int cnt = __popc(nbrmask);

@@ -240,7 +240,7 @@ qd_k_percentile(const int* __restrict__ env_ids, long n, const double* __restric
     double res[2];
     for (int which = 0; which < 2; ++which) {
         const double q = (which == 0 ? 0.5 : 99.5) / 100.0;
-        const double virt = ((double)n * q + (1.0 + q * (1.0 - 1.0 - 1.0))) - 1.0;   // numpy _compute_virtual_index
+        const double virt = (double)(n - 1) * q;             // numpy 'linear' method: (n-1)*quantile
         const double prev = floor(virt);
         long ip = (long)prev; if (ip < 0) ip = 0; if (ip > n - 1) ip = n - 1;
         long in = ip + 1; if (in > n - 1) in = n - 1;

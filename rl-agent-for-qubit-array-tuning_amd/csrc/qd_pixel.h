@@ -117,10 +117,16 @@ QD_HD void qd_pixel_front(const double* par, const double* st, int ch, int R, in
 // delta in {-1,0,1,2}^N, c >= 0, keeping the 32 smallest by (E, index) where
 // index = sum_i (delta_i+1) << 2(N-1-i).  Equivalent to the reference's scan of
 // all 4^N candidates with stable sorts (proved against the oracle in tests), but
-// done as a depth-first Schnorr-Euchner enumeration: with A = U U^T (U upper),
-// E = sum_i ((U^T d)_i)^2 and (U^T d)_i depends on d_0..d_i only, so the partial
-// sums are lower bounds and whole sub-trees are pruned against the current 32nd
-// best.  Partial sums are only used to PRUNE (with a relative safety margin);
+// done as a depth-first branch and bound:
+//   E(c) = E(m) + g.(c-m) + (c-m)^T A (c-m),   m = n_cont,  g = 2 A (m - v')
+// (exact for any m).  With A = U U^T (U upper) the quadratic part is
+// sum_i ((U^T (c-m))_i)^2 where term i depends on dots 0..i only, and the linear
+// part is separable, so  sum_{i<=L} [t_i^2 + g_i (c_i-m_i)] + tail_L  with
+// tail_L = sum_{j>L} min_c g_j (c_j-m_j)  is a lower bound of E - E(m) for the
+// whole sub-tree.  m is the (approximate) constrained continuous minimiser, so
+// the bound stays tight when dots are clipped empty (g_i > 0 there) -- without
+// the linear term the search degenerates to ~3^N leaves in that regime.
+// Bounds are only used to PRUNE (with a safety margin that covers round-off);
 // every candidate that reaches a leaf gets its canonical energy, so the kept
 // list is bit-identical to the brute-force scan.
 // The top-k buffer is caller-provided strided storage (LDS on the GPU).
@@ -129,11 +135,13 @@ template <int N>
 struct QdSearch {
     const double* A; int lda;        // cdd_inv (row-major, lda = G)
     const double* U;                 // N*N row-major upper factor
-    double fl[N], vdash[N], d[N];
+    double fl[N], vdash[N], m[N], g[N], tail[N];
+    double dm[N], dv[N];             // current path: c - m, c - v'
+    double Em;
     double* e; int es;               // energies, stride
     uint16_t* id; int is;            // indices, stride
     int count;
-    double bound, lim;
+    double lim;                      // prune when (partial + tail) > lim   (relative to Em)
     unsigned idx;
     unsigned long long nodes, leaves, inserts;   // statistics (host harness only)
 };
@@ -141,8 +149,8 @@ struct QdSearch {
 template <int N>
 QD_HD void qd_search_set_bound(QdSearch<N>& S) {
     if (S.count == QD_K) {
-        S.bound = S.e[(QD_K - 1) * S.es];
-        S.lim = S.bound + (fabs(S.bound) * 1e-11 + 1e-300);
+        const double bound = S.e[(QD_K - 1) * S.es];
+        S.lim = (bound - S.Em) + ((fabs(bound) + fabs(S.Em)) * 1e-11 + 1e-300);
     }
 }
 
@@ -178,38 +186,36 @@ struct QdLevel {
 #endif
         double s = 0.0;
 #pragma unroll
-        for (int j = 0; j < L; ++j) s = fma(S.U[j * N + L], S.d[j], s);
+        for (int j = 0; j < L; ++j) s = fma(S.U[j * N + L], S.dm[j], s);
         const double uLL = S.U[L * N + L];
-        // the four choices delta = k-1, k = 0..3
-        double dk0 = (S.fl[L] + -1.0) - S.vdash[L];
-        double dk1 = (S.fl[L] + 0.0) - S.vdash[L];
-        double dk2 = (S.fl[L] + 1.0) - S.vdash[L];
-        double dk3 = (S.fl[L] + 2.0) - S.vdash[L];
-        double t0 = fma(uLL, dk0, s), t1 = fma(uLL, dk1, s), t2 = fma(uLL, dk2, s), t3 = fma(uLL, dk3, s);
-        double a0 = fabs(t0), a1 = fabs(t1), a2 = fabs(t2), a3 = fabs(t3);
+        const double base = S.fl[L] - S.m[L];              // c - m for delta = 0
+        const double gL = S.g[L];
+        // increment f(k) = t^2 + g (c-m) of the four choices delta = k-1
+        double f0, f1, f2, f3;
+        { const double x = base - 1.0, t = fma(uLL, x, s); f0 = fma(t, t, gL * x); }
+        { const double x = base,       t = fma(uLL, x, s); f1 = fma(t, t, gL * x); }
+        { const double x = base + 1.0, t = fma(uLL, x, s); f2 = fma(t, t, gL * x); }
+        { const double x = base + 2.0, t = fma(uLL, x, s); f3 = fma(t, t, gL * x); }
         int k0 = 0, k1 = 1, k2 = 2, k3 = 3;
-        // sort (a, t, dk, k) ascending by a: 5-comparator network
 #define QD_CSWAP(i, j)                                                             \
-        if (a##j < a##i) {                                                         \
-            double ta = a##i; a##i = a##j; a##j = ta;                              \
-            double tt = t##i; t##i = t##j; t##j = tt;                              \
-            double td = dk##i; dk##i = dk##j; dk##j = td;                          \
-            int tk = k##i; k##i = k##j; k##j = tk;                                 \
-        }
+        if (f##j < f##i) { double tf = f##i; f##i = f##j; f##j = tf; int tk = k##i; k##i = k##j; k##j = tk; }
         QD_CSWAP(0, 1) QD_CSWAP(2, 3) QD_CSWAP(0, 2) QD_CSWAP(1, 3) QD_CSWAP(1, 2)
 #undef QD_CSWAP
+        // only the visiting order and the increments stay live across the recursion
         const bool no_minus = !(S.fl[L] > 0.0);            // delta = -1 would give c < 0
         const unsigned sh = 2u * (unsigned)(N - 1 - L);
+        const double tl = S.tail[L];
         // ONE call site per level (a 4x unrolled visit would inline 4^N leaves)
 #pragma unroll 1
         for (int r = 0; r < 4; ++r) {
-            const double tr = r == 0 ? t0 : r == 1 ? t1 : r == 2 ? t2 : t3;
-            const double dr = r == 0 ? dk0 : r == 1 ? dk1 : r == 2 ? dk2 : dk3;
+            const double fr = r == 0 ? f0 : r == 1 ? f1 : r == 2 ? f2 : f3;
             const int kr = r == 0 ? k0 : r == 1 ? k1 : r == 2 ? k2 : k3;
             if (kr == 0 && no_minus) continue;
-            const double pn = fma(tr, tr, partial);
-            if (pn > S.lim) return;                          // choices are in increasing |t|
-            S.d[L] = dr;
+            const double pn = partial + fr;
+            if (pn + tl > S.lim) return;                     // choices are in increasing f
+            const double c = S.fl[L] + (double)(kr - 1);
+            S.dm[L] = c - S.m[L];
+            S.dv[L] = c - S.vdash[L];
             S.idx = (S.idx & ~(3u << sh)) | ((unsigned)kr << sh);
             QdLevel<N, L + 1>::run(S, pn);
         }
@@ -225,8 +231,8 @@ struct QdLevel<N, N> {
         double E = 0.0;
 #pragma unroll
         for (int i = 0; i < N; ++i) {
-            double t = qd_dotN<N>(S.A + i * S.lda, S.d);
-            E = fma(S.d[i], t, E);
+            double t = qd_dotN<N>(S.A + i * S.lda, S.dv);
+            E = fma(S.dv[i], t, E);
         }
         qd_search_insert(S, E, S.idx);
     }
@@ -241,13 +247,38 @@ QD_HD int qd_candidates(const double* par, const double* vpp, const double* ncon
     const QdLayout L = qd_layout(N);
     QdSearch<N> S;
     S.A = par + L.cdd_inv; S.lda = N + 1; S.U = par + L.ufac;
+    bool shifted = false;
 #pragma unroll
     for (int i = 0; i < N; ++i) {
-        S.fl[i] = floor(ncont[i]); S.vdash[i] = vpp[i]; S.d[i] = 0.0;
+        S.fl[i] = floor(ncont[i]); S.vdash[i] = vpp[i]; S.m[i] = ncont[i];
+        S.dm[i] = 0.0; S.dv[i] = 0.0; S.g[i] = 0.0; S.tail[i] = 0.0;
         fl_out[i] = (int32_t)S.fl[i];
+        if (ncont[i] != vpp[i]) shifted = true;
+    }
+    S.Em = 0.0;
+    if (shifted) {                                         // some dot is clipped: m != v'
+        double mv[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) mv[i] = S.m[i] - S.vdash[i];
+        double Em = 0.0;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const double t = qd_dotN<N>(S.A + i * S.lda, mv);
+            S.g[i] = 2.0 * t;
+            Em = fma(mv[i], t, Em);
+        }
+        S.Em = Em;
+        double acc = 0.0;
+#pragma unroll
+        for (int j = N - 1; j >= 0; --j) {
+            S.tail[j] = acc;                               // sum over levels > j
+            const double cmin = S.fl[j] > 0.0 ? S.fl[j] - 1.0 : 0.0, cmax = S.fl[j] + 2.0;
+            const double lo = S.g[j] * (cmin - S.m[j]), hi = S.g[j] * (cmax - S.m[j]);
+            acc += lo < hi ? lo : hi;
+        }
     }
     S.e = e; S.es = es; S.id = id; S.is = is;
-    S.count = 0; S.bound = INFINITY; S.lim = INFINITY; S.idx = 0;
+    S.count = 0; S.lim = INFINITY; S.idx = 0;
     S.nodes = S.leaves = S.inserts = 0;
     QdLevel<N, 0>::run(S, 0.0);
 #ifndef __HIP_DEVICE_COMPILE__

@@ -55,6 +55,13 @@ def lib():
         raise QdError(
             f"{LIB_PATH} not found: build it with `make -C {CSRC}` (or __graft_entry__.build()). "
             "qadapt_hip has no CPU fallback.")
+    # libqdsim.so needs libamdhip64.so.7.  PyTorch-ROCm ships its own copy with that
+    # soname; loading torch first makes the dynamic loader reuse it, so device
+    # pointers and streams are shared with torch instead of living in a second runtime.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = ctypes.CDLL(LIB_PATH)
     vp, ip, fp, dp = ctypes.c_void_p, ctypes.POINTER(ctypes.c_int32), ctypes.c_void_p, ctypes.c_void_p
     L.qd_param_block_doubles.argtypes = [ctypes.c_int]; L.qd_param_block_doubles.restype = ctypes.c_int

@@ -49,7 +49,7 @@ def test_c_8dot_small():
 
 def test_c_normalise_matches_numpy():
     rng = np.random.default_rng(3)
-    for shape in [(7, 64 * 64), (1, 32 * 32), (3, 100)]:
+    for shape in [(7, 64 * 64), (1, 32 * 32), (3, 100), (5, 144), (1, 577), (3, 4115), (1, 10)]:
         z = rng.normal(size=shape) ** 3
         out, pl = OC.normalise(z)
         assert pl[0] == np.percentile(z, 0.5) and pl[1] == np.percentile(z, 99.5)
