@@ -101,20 +101,28 @@ __device__ __forceinline__ double qd_seg_max(double v, unsigned seg, int smax, v
 }
 
 // Sturm count (number of eigenvalues < lam) of the k x k tridiagonal whose rows
-// live at the member lanes of `seg` (ascending order).
+// live at the member lanes of `seg` (ascending order).  Division-free: sign
+// changes of the leading-minor polynomials p_i = (a_i - lam) p_{i-1} - b_{i-1}^2 p_{i-2}
+// (one dependent fma per row), rescaled to stay inside the float64 range.
 __device__ __forceinline__ int qd_sturm(double lam, unsigned seg, int k, int kmax,
                                         volatile const double* al, volatile const double* be, int hb) {
     unsigned mm = seg;
     int cnt = 0;
-    double d = 1.0, bprev = 0.0;
+    double p = 1.0, pm = 0.0, bprev = 0.0;
+    bool neg = false;
     for (int i = 0; i < kmax; ++i) {
         if (i < k) {
-            int b = __builtin_ctz(mm); mm &= mm - 1;
-            double a = al[hb + b];
-            double q = (i == 0) ? 0.0 : (bprev * bprev) * qd_rcp(d);
-            d = (a - lam) - q;
-            if (d == 0.0) d = -1e-300;
-            cnt += d < 0.0;
+            const int b = __builtin_ctz(mm); mm &= mm - 1;
+            const double a = al[hb + b];
+            const double u = (bprev * bprev) * pm;
+            double pn = fma(a - lam, p, -u);
+            const bool nneg = (pn == 0.0) ? !neg : (pn < 0.0);
+            cnt += nneg != neg;
+            neg = nneg;
+            pm = p; p = pn;
+            const double ap = fabs(p);
+            if (ap > 1e100) { p *= 1e-100; pm *= 1e-100; }
+            else if (ap < 1e-100 && ap > 0.0) { p *= 1e100; pm *= 1e100; }
             bprev = be[hb + b];
         }
     }

@@ -118,7 +118,7 @@ qd_k_candidates(const int* __restrict__ env_ids, int env_base, int R, const doub
 #define QD_GS_PPB 64            // pixels per block: 8 half-waves x 8 pixels
 
 template <int N>
-__global__ void __launch_bounds__(QD_GS_BLOCK)
+__global__ void __launch_bounds__(QD_GS_BLOCK, 3)
 qd_k_ground(const int* __restrict__ env_ids, int env_base, int R, const double* __restrict__ params,
             const QdPixelRec* __restrict__ recs, double* __restrict__ zraw, double* __restrict__ occ_out) {
     constexpr int G = N + 1;

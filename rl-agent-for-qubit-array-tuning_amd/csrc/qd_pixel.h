@@ -201,20 +201,22 @@ struct QdLevel {
         if (f##j < f##i) { double tf = f##i; f##i = f##j; f##j = tf; int tk = k##i; k##i = k##j; k##j = tk; }
         QD_CSWAP(0, 1) QD_CSWAP(2, 3) QD_CSWAP(0, 2) QD_CSWAP(1, 3) QD_CSWAP(1, 2)
 #undef QD_CSWAP
-        // only the visiting order and the increments stay live across the recursion
-        const bool no_minus = !(S.fl[L] > 0.0);            // delta = -1 would give c < 0
+        // only the packed visiting order stays live across the recursion; the increment of
+        // the visited choice is recomputed (same expression, same bits) to save registers
+        const unsigned order = (unsigned)k0 | ((unsigned)k1 << 2) | ((unsigned)k2 << 4) | ((unsigned)k3 << 6);
         const unsigned sh = 2u * (unsigned)(N - 1 - L);
-        const double tl = S.tail[L];
         // ONE call site per level (a 4x unrolled visit would inline 4^N leaves)
 #pragma unroll 1
         for (int r = 0; r < 4; ++r) {
-            const double fr = r == 0 ? f0 : r == 1 ? f1 : r == 2 ? f2 : f3;
-            const int kr = r == 0 ? k0 : r == 1 ? k1 : r == 2 ? k2 : k3;
-            if (kr == 0 && no_minus) continue;
-            const double pn = partial + fr;
-            if (pn + tl > S.lim) return;                     // choices are in increasing f
-            const double c = S.fl[L] + (double)(kr - 1);
-            S.dm[L] = c - S.m[L];
+            const int kr = (int)((order >> (2 * r)) & 3u);
+            const double flL = S.fl[L];
+            if (kr == 0 && !(flL > 0.0)) continue;           // delta = -1 would give c < 0
+            const double c = flL + (double)(kr - 1);
+            const double x = (flL - S.m[L]) + (double)(kr - 1);
+            const double t = fma(S.U[L * N + L], x, s);
+            const double pn = partial + fma(t, t, S.g[L] * x);
+            if (pn + S.tail[L] > S.lim) return;              // choices are in increasing f
+            S.dm[L] = x;
             S.dv[L] = c - S.vdash[L];
             S.idx = (S.idx & ~(3u << sh)) | ((unsigned)kr << sh);
             QdLevel<N, L + 1>::run(S, pn);
