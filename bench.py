@@ -98,7 +98,9 @@ def main():
 
     N, R, B = args.dots, args.resolution, args.envs
     dev = torch.device(f"cuda:{local}")
-    env = VecQuantumDeviceEnv(B, num_dots=N, resolution=R, device=dev, seed=1234, env_id_offset=rank * B,
+    from qadapt_hip import shard as _shard
+    first_env, _ = _shard.shard_env_ids(rank, world, B)
+    env = VecQuantumDeviceEnv(B, num_dots=N, resolution=R, device=dev, seed=1234, env_id_offset=first_env,
                               capacitance_model=SyntheticCapacitanceModel(99 + rank))
     gen = torch.Generator(device="cpu").manual_seed(99 + rank)
     env.reset()
@@ -121,10 +123,8 @@ def main():
         dist.barrier()
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
-    if dist:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    from qadapt_hip import shard
+    dt = shard.max_over_ranks(dt, device=dev)          # identity when not distributed
 
     if rank == 0:
         total_env_steps = B * world * args.steps

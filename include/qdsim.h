@@ -130,6 +130,7 @@ int qd_get_candidates(qd_handle* h, int32_t* states_host);
  * kernel (ground state) on the current data and returns the mean duration in
  * milliseconds measured with HIP events on `stream`. */
 int qd_time_ground_kernel(qd_handle* h, int iters, float* mean_ms, void* stream);
+int qd_time_candidates_kernel(qd_handle* h, int iters, float* mean_ms, void* stream);
 
 #ifdef __cplusplus
 }

@@ -323,3 +323,27 @@ extern "C" int qd_time_ground_kernel(qd_handle* h, int iters, float* mean_ms, vo
     *mean_ms = ms / iters;
     return QD_OK;
 }
+
+extern "C" int qd_time_candidates_kernel(qd_handle* h, int iters, float* mean_ms, void* stream) {
+    if (!h || iters < 1 || !mean_ms) return QD_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    QD_HIP(hipSetDevice(h->device));
+    hipEvent_t a, b;
+    QD_HIP(hipEventCreate(&a)); QD_HIP(hipEventCreate(&b));
+    const int cnt = h->chunk < h->B ? h->chunk : h->B;
+    const QdLayout& L = h->L;
+    const size_t shm = sizeof(double) * (L.size + L.s_size) + (size_t)QD_K * QD_CAND_BLOCK * (sizeof(double) + sizeof(uint16_t));
+    dim3 g1((h->P + QD_CAND_BLOCK - 1) / QD_CAND_BLOCK, h->C, cnt);
+    QD_HIP(hipEventRecord(a, s));
+    for (int i = 0; i < iters; ++i) {
+        QD_DISPATCH_N(h->N, qd_k_candidates<NN><<<g1, dim3(QD_CAND_BLOCK), shm, s>>>(nullptr, 0, h->R, h->params, h->state, h->recs));
+    }
+    QD_HIP(hipGetLastError());
+    QD_HIP(hipEventRecord(b, s));
+    QD_HIP(hipEventSynchronize(b));
+    float ms = 0.f;
+    QD_HIP(hipEventElapsedTime(&ms, a, b));
+    hipEventDestroy(a); hipEventDestroy(b);
+    *mean_ms = ms / iters;
+    return QD_OK;
+}

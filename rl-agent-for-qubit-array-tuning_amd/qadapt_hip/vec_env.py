@@ -276,3 +276,9 @@ class VecQuantumDeviceEnv:
         _lib.check(self._h, self._lib.qd_time_ground_kernel(self._h, iters, ctypes.byref(ms), self._stream()),
                    "qd_time_ground_kernel")
         return float(ms.value)
+
+    def time_candidates_kernel(self, iters=3):
+        ms = ctypes.c_float(0)
+        _lib.check(self._h, self._lib.qd_time_candidates_kernel(self._h, iters, ctypes.byref(ms), self._stream()),
+                   "qd_time_candidates_kernel")
+        return float(ms.value)

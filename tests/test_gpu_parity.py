@@ -264,3 +264,35 @@ def test_wild_regime_ground_energy_not_above_oracle(N, R):
             tot = occ[e, ch].sum(axis=1)
             assert np.mean(np.abs(tot - np.round(tot)) < 1e-6) > 0.98
     env.close()
+
+
+def test_multi_agent_wrapper_end_to_end_on_gpu(tmp_path):
+    """The reference-surface wrapper over the HIP env: per-agent observations built by the
+    host mirror equal the per-agent tensors the kernel writes, step structure is RLlib's."""
+    import yaml
+    from qadapt_hip import device_model as DM
+    from qadapt_hip.env import QuantumDeviceEnv
+    from qadapt_hip.multi_agent import MultiAgentEnvWrapper
+    from qadapt_hip.vec_env import SyntheticCapacitanceModel
+    N, R = 4, 16
+    cfg = DM.load_yaml(None, "env_config.yaml")
+    cfg["simulator"].update(num_dots=N, resolution=R, max_steps=2)
+    p = tmp_path / "env.yaml"; p.write_text(yaml.safe_dump(cfg))
+    w = MultiAgentEnvWrapper(return_voltage=True, env_config_path=str(p), base_env_class=QuantumDeviceEnv,
+                             capacitance_model=SyntheticCapacitanceModel(5))
+    obs, infos = w.reset()
+    vec = w.base_env._b
+    pim = vec.plunger_images.cpu().numpy()[0]; bim = vec.barrier_images.cpu().numpy()[0]
+    for i in range(N):
+        assert np.array_equal(obs[f"plunger_{i}"]["image"], pim[i])
+    for j in range(N - 1):
+        assert np.array_equal(obs[f"barrier_{j}"]["image"], bim[j])
+    acts = {a: np.array([0.0], np.float32) for a in w.all_agent_ids}
+    obs, rew, term, trunc, infos = w.step(acts)
+    assert set(rew) == set(w.all_agent_ids) and all(0.0 <= r <= 1.0 for r in rew.values())
+    assert trunc["__all__"] is False and "ground_truth" in infos["plunger_0"]
+    obs, rew, term, trunc, infos = w.step(acts)
+    assert trunc["__all__"] is True and term["__all__"] is False
+    obs, infos = w.reset()
+    assert obs["plunger_0"]["image"].shape == (R, R, 2)
+    w.close()
