@@ -9,6 +9,13 @@
 #else
 #define QD_HD inline
 #endif
+// keeps the scheduler from hoisting a whole matrix of LDS loads in front of an
+// unrolled row loop (register pressure); no-op on the host
+#if defined(__HIP_DEVICE_COMPILE__)
+#define QD_ROW_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define QD_ROW_FENCE() ((void)0)
+#endif
 
 #define QD_MAXN 8            // dots
 #define QD_K 32              // kept charge states   (qarray_config.yaml:129)

@@ -42,6 +42,9 @@ struct QdWaveLds {
     double buf[64];                 // publish buffer for per-component reductions
     double al[64], be[64];          // T: alpha_r / beta_r at the r-th member lane
     double rd[64], lf[64], yv[64];  // inverse iteration: 1/d_i, l_i, y_i at member slots
+    double ib[64];                  // 1/beta_r at the r-th member lane (pass-2 replay)
+    double pv[2][16];               // per half: vpp[0..N] (cgd @ v_ext) then tc[0..N-2] at offset 9
+    int pfl[2][8];                  // per half: floor(n_cont)
 };
 
 __device__ __forceinline__ unsigned qd_half_ballot(bool p) {
@@ -53,6 +56,15 @@ __device__ __forceinline__ double qd_rcp(double x) {
     r = fma(fma(-x, r, 1.0), r, r);
     r = fma(fma(-x, r, 1.0), r, r);
     return r;
+}
+// sqrt(x) and 1/sqrt(x) from one v_rsq_f64 + two Newton steps (x > 0); ~1 ulp
+__device__ __forceinline__ void qd_sqrt_rsqrt(double x, double& s, double& r) {
+    double y = __builtin_amdgcn_rsq(x);
+    y = y * fma(-0.5 * x * y, y, 1.5);
+    y = y * fma(-0.5 * x * y, y, 1.5);
+    r = y;
+    s = x * y;
+    s = fma(fma(-s, s, x), 0.5 * y, s);            // one correction step for sqrt
 }
 __device__ __forceinline__ double qd_half_min(double v) {
 #pragma unroll
@@ -143,24 +155,37 @@ __device__ void qd_ground_pixel(const double* __restrict__ A, const QdPixelRec* 
     volatile double* buf = W.buf;
 
     // ---- 1. my state -------------------------------------------------------
+    // pixel-uniform record fields go through LDS once (keeps them out of registers)
+    const int hh = hb >> 5;
+    if (m < N + 1) W.pv[hh][m] = rec->vpp[m];
+    else if (m >= 9 && m < 9 + N - 1) W.pv[hh][m] = rec->tc[m - 9];
+    if (m >= 16 && m < 16 + N) W.pfl[hh][m - 16] = rec->fl[m - 16];
+    __builtin_amdgcn_wave_barrier();
+    const double* pvv = W.pv[hh];
     const int nvalid = rec->nvalid;
     const bool valid = m < nvalid;
     const unsigned code = valid ? (unsigned)rec->idx[m] : 0u;
     int n[N];
-    double dd[N];
     unsigned ecode = 0;
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-        const int dig = (code >> (2 * (N - 1 - i))) & 3;
-        n[i] = valid ? rec->fl[i] + dig - 1 : 0;
-        dd[i] = (double)n[i] - rec->vpp[i];
-        ecode |= (unsigned)dig << (4 * (N - 1 - i));
-    }
     double F = 0.0;
+    {
+        double dd[N];
 #pragma unroll
-    for (int i = 0; i < N; ++i) {
-        double t = qd_dotN<N>(A + i * G, dd);
-        F = fma(dd[i], t, F);
+        for (int i = 0; i < N; ++i) {
+            const int dig = (code >> (2 * (N - 1 - i))) & 3;
+            n[i] = valid ? W.pfl[hh][i] + dig - 1 : 0;
+            dd[i] = (double)n[i] - pvv[i];
+            ecode |= (unsigned)dig << (4 * (N - 1 - i));
+        }
+        // rolled over rows: a fully unrolled N x N form keeps all of A in registers
+#pragma unroll 1
+        for (int i = 0; i < N; ++i) {
+            double t = qd_dotN<N>(A + i * G, dd);
+            double di = dd[0];
+#pragma unroll
+            for (int j = 1; j < N; ++j) di = (j == i) ? dd[j] : di;
+            F = fma(di, t, F);
+        }
     }
 
     // ---- 2. hop neighbours -------------------------------------------------
@@ -168,8 +193,9 @@ __device__ void qd_ground_pixel(const double* __restrict__ A, const QdPixelRec* 
     // limit tc == 0 exactly diagonal, as a dense eigh of a diagonal matrix would)
     unsigned tcnz = 0;
 #pragma unroll
-    for (int d = 0; d < N - 1; ++d) tcnz |= (rec->tc[d] != 0.0 ? 1u : 0u) << d;
+    for (int d = 0; d < N - 1; ++d) tcnz |= (pvv[9 + d] != 0.0 ? 1u : 0u) << d;
     unsigned nbrmask = 0;
+#pragma unroll 4
     for (int j = 0; j < 32; ++j) {
         const unsigned cj = __shfl(ecode, j, 32);
         const int Y = (int)cj - (int)ecode;
@@ -196,7 +222,7 @@ __device__ void qd_ground_pixel(const double* __restrict__ A, const QdPixelRec* 
                 int nd = 0, nd1 = 0;
 #pragma unroll
                 for (int i = 0; i < N; ++i) { if (i == d) nd = n[i]; if (i == d + 1) nd1 = n[i]; }
-                const double t = rec->tc[d];
+                const double t = pvv[9 + d];
                 // Y < 0: s_j = s_i - e_d + e_{d+1} (forward); else backward
                 const double prod = (Y < 0) ? (double)nd * ((double)nd1 + 1.0)
                                             : (double)nd1 * ((double)nd + 1.0);
@@ -235,7 +261,7 @@ __device__ void qd_ground_pixel(const double* __restrict__ A, const QdPixelRec* 
     const bool solve = active && ssz > 1;
     const double q0 = solve ? 1.0 / sqrt((double)ssz) : 0.0;
     double q = q0, qp = 0.0, bp = 0.0, anorm = 0.0;
-    double al_mine = F, be_mine = 0.0;                     // singleton: T = [F]
+    double al_mine = F, be_mine = 0.0, ib_mine = 0.0;      // singleton: T = [F]
     int k = solve ? 0 : 1;
     bool done = !solve;
     const int jmax = qd_wave_max_int(solve ? ssz : 0);
@@ -248,21 +274,24 @@ __device__ void qd_ground_pixel(const double* __restrict__ A, const QdPixelRec* 
         }
         const double a = qd_seg_sum(q * w, seg, smax, buf, hb);
         w = w - a * q - bp * qp;
-        const double b = sqrt(qd_seg_sum(w * w, seg, smax, buf, hb));
+        const double b2 = qd_seg_sum(w * w, seg, smax, buf, hb);
+        double b = 0.0, ib = 0.0;
+        if (b2 > 0.0) qd_sqrt_rsqrt(b2, b, ib);
         if (!done) {
             anorm = fmax(anorm, fmax(fabs(a), b));
-            if (r == j) { al_mine = a; be_mine = b; }
+            if (r == j) { al_mine = a; be_mine = b; ib_mine = ib; }
             k = j + 1;
             if (j + 1 >= ssz || !(b > 1e-13 * anorm)) {
                 done = true;
                 if (r == j) be_mine = 0.0;
             } else {
-                qp = q; bp = b; q = w * qd_rcp(b);
+                qp = q; bp = b; q = w * ib;
             }
         }
     }
     W.al[lane] = al_mine;
     W.be[lane] = (r < k - 1) ? be_mine : 0.0;
+    W.ib[lane] = ib_mine;
     __builtin_amdgcn_wave_barrier();
     volatile const double* al = W.al;
     volatile const double* be = W.be;
@@ -402,6 +431,8 @@ __device__ void qd_ground_pixel(const double* __restrict__ A, const QdPixelRec* 
     }
 
     // ---- 7. Lanczos pass 2: x = sum_j y_j q_j -------------------------------
+    // The recurrence is replayed with the alpha_j / beta_j stored by pass 1 (same
+    // operations, same bits as pass 1, without its two reductions per step).
     double x = solve ? 0.0 : 1.0;
     {
         double q2 = q0, qp2 = 0.0, bp2 = 0.0;
@@ -409,20 +440,18 @@ __device__ void qd_ground_pixel(const double* __restrict__ A, const QdPixelRec* 
         unsigned mm = seg;
         for (int j = 0; j < jmax; ++j) {
             if (!__any(!done2)) break;
-            double yj = 0.0;
-            if (!done2) { const int b = __builtin_ctz(mm); mm &= mm - 1; yj = W.yv[hb + b]; }
+            double yj = 0.0, a = 0.0, b = 0.0, ib = 0.0;
+            if (!done2) { const int bb = __builtin_ctz(mm); mm &= mm - 1; yj = W.yv[hb + bb]; a = al[hb + bb]; b = be[hb + bb]; ib = W.ib[hb + bb]; }
             double w = F * q2;
             for (int s = 0; s < maxcnt; ++s) {
                 const double qj = __shfl(q2, (int)W.nidx[s][lane], 32);
                 w = fma(W.coef[s][lane], qj, w);
             }
-            const double a = qd_seg_sum(q2 * w, seg, smax, buf, hb);
             w = w - a * q2 - bp2 * qp2;
-            const double b = sqrt(qd_seg_sum(w * w, seg, smax, buf, hb));
             if (!done2) {
                 x = fma(yj, q2, x);
                 if (j + 1 >= k) done2 = true;
-                else { qp2 = q2; bp2 = b; q2 = w * qd_rcp(b); }
+                else { qp2 = q2; bp2 = b; q2 = w * ib; }       // same operands as pass 1: same bits
             }
         }
     }

@@ -118,7 +118,7 @@ qd_k_candidates(const int* __restrict__ env_ids, int env_base, int R, const doub
 #define QD_GS_PPB 64            // pixels per block: 8 half-waves x 8 pixels
 
 template <int N>
-__global__ void __launch_bounds__(QD_GS_BLOCK, 3)
+__global__ void __launch_bounds__(QD_GS_BLOCK)
 qd_k_ground(const int* __restrict__ env_ids, int env_base, int R, const double* __restrict__ params,
             const QdPixelRec* __restrict__ recs, double* __restrict__ zraw, double* __restrict__ occ_out) {
     constexpr int G = N + 1;
@@ -146,17 +146,19 @@ qd_k_ground(const int* __restrict__ env_ids, int env_base, int R, const double* 
         double occ[N], lam;
         qd_ground_pixel<N>(sA, rec, W, occ, &lam);
         if ((threadIdx.x & 31) == 0 && p < P) {
-            // sensor stage (closed-form differences, qd_pixel.h)
-            const double Ns = rint(rec->vpp[N]);
+            // sensor stage (closed-form differences, qd_pixel.h); vpp staged in LDS by qd_ground_pixel
+            const double* pvv = W.pv[(threadIdx.x >> 5) & 1];
+            const double vs = pvv[N];
+            const double Ns = rint(vs);
             double b = 0.0;
 #pragma unroll
-            for (int i = 0; i < N; ++i) b = fma(sA[N * G + i], occ[i] - rec->vpp[i], b);
+            for (int i = 0; i < N; ++i) b = fma(sA[N * G + i], occ[i] - pvv[i], b);
             const double a = sA[N * G + N];
             const double gamma = sA[G * G];
             double s = 0.0;
 #pragma unroll
             for (int k = -QD_NPEAK; k < QD_NPEAK; ++k) {
-                const double xk = (Ns + (double)k) - rec->vpp[N];
+                const double xk = (Ns + (double)k) - vs;
                 const double dF = 2.0 * b + a * (2.0 * xk + 1.0);
                 const double rr = dF / gamma;
                 s += 1.0 / (rr * rr + 1.0);

@@ -70,11 +70,11 @@ QD_HD void qd_pixel_front(const double* par, const double* st, int ch, int R, in
         if (i == ch + 1) Vd[i] = sy;
     }
 #pragma unroll
-    for (int i = 0; i < G; ++i) v_ext[i] = qd_dotN<G>(vgm + i * G, Vd) + par[L.origin + i];
+    for (int i = 0; i < G; ++i) { v_ext[i] = qd_dotN<G>(vgm + i * G, Vd) + par[L.origin + i]; QD_ROW_FENCE(); }
 #pragma unroll
     for (int b = 0; b < NB; ++b) v_ext[G + b] = barrier_v[b];
 #pragma unroll
-    for (int i = 0; i < G; ++i) vpp[i] = qd_dotN<V>(par + L.cgd + i * V, v_ext);
+    for (int i = 0; i < G; ++i) { vpp[i] = qd_dotN<V>(par + L.cgd + i * V, v_ext); QD_ROW_FENCE(); }
     // a8 continuous ground state
     bool all_pos = true;
 #pragma unroll
@@ -85,7 +85,7 @@ QD_HD void qd_pixel_front(const double* par, const double* st, int ch, int R, in
 #pragma unroll
         for (int i = 0; i < N; ++i) n[i] = vpp[i] > 0.0 ? vpp[i] : 0.0;
 #pragma unroll
-        for (int i = 0; i < N; ++i) g2[i] = qd_dotN<N>(A + i * G, vpp);
+        for (int i = 0; i < N; ++i) { g2[i] = qd_dotN<N>(A + i * G, vpp); QD_ROW_FENCE(); }
         for (int it = 0; it < 50; ++it) {
 #pragma unroll
             for (int i = 0; i < N; ++i) {
@@ -93,6 +93,7 @@ QD_HD void qd_pixel_front(const double* par, const double* st, int ch, int R, in
                 double grad = g1 - g2[i];
                 double v = n[i] - 0.1 * grad;
                 nn[i] = v > 0.0 ? v : 0.0;
+                QD_ROW_FENCE();
             }
 #pragma unroll
             for (int i = 0; i < N; ++i) n[i] = nn[i];
@@ -108,6 +109,7 @@ QD_HD void qd_pixel_front(const double* par, const double* st, int ch, int R, in
     for (int b = 0; b < NB; ++b) {
         double vb_eff = barrier_v[b] + qd_dotN<G>(par + L.cbg + b * G, v_ext);
         tc[b] = tc_base * exp(-par[L.alpha + b] * vb_eff);
+        QD_ROW_FENCE();
     }
 }
 
@@ -268,6 +270,7 @@ QD_HD int qd_candidates(const double* par, const double* vpp, const double* ncon
             const double t = qd_dotN<N>(S.A + i * S.lda, mv);
             S.g[i] = 2.0 * t;
             Em = fma(mv[i], t, Em);
+            QD_ROW_FENCE();
         }
         S.Em = Em;
         double acc = 0.0;
