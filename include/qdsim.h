@@ -62,8 +62,8 @@ typedef struct qd_config {
  * layout is documented in csrc/qd_common.h (mirrored by qadapt_hip/layout.py). */
 int qd_param_block_doubles(int n_dot);
 int qd_state_block_doubles(int n_dot);
-/* Writes the 27 layout integers (see qadapt_hip/layout.py LAYOUT_FIELDS). */
-int qd_layout_query(int n_dot, int32_t* out27);
+/* Writes the 28 layout integers (see qadapt_hip/layout.py LAYOUT_FIELDS). */
+int qd_layout_query(int n_dot, int32_t* out28);
 
 /* QuantumDeviceEnv.__init__ (env.py:38-132): allocates device state for B envs
  * on GPU `device`; Kalman filters start at their priors (env.py:779-787). */

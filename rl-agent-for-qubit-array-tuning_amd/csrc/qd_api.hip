@@ -192,6 +192,11 @@ extern "C" int qd_apply_actions(qd_handle* h, const float* actions, double* rewa
     return QD_OK;
 }
 
+static int qd_cand_blocks(int R) {
+    const int tiles = ((R + 7) / 8) * ((R + 7) / 8), per_block = QD_CAND_BLOCK / 64;
+    return (tiles + per_block - 1) / per_block;
+}
+
 static int qd_launch_ground(qd_handle* h, const int32_t* env_ids, int base, int cnt, hipStream_t s) {
     dim3 g2((h->P + QD_GS_PPB - 1) / QD_GS_PPB, h->C, cnt);
     QD_DISPATCH_N(h->N, qd_k_ground<NN><<<g2, dim3(QD_GS_BLOCK), 0, s>>>(env_ids, base, h->R,
@@ -211,7 +216,7 @@ extern "C" int qd_observe(qd_handle* h, const int32_t* env_ids, int n, void* str
     const size_t shm = sizeof(double) * (L.size + L.s_size) + (size_t)QD_K * QD_CAND_BLOCK * (sizeof(double) + sizeof(uint16_t));
     for (int base = 0; base < n; base += h->chunk) {
         const int cnt = (n - base < h->chunk) ? n - base : h->chunk;
-        dim3 g1((h->P + QD_CAND_BLOCK - 1) / QD_CAND_BLOCK, h->C, cnt);
+        dim3 g1(qd_cand_blocks(h->R), h->C, cnt);
         QD_DISPATCH_N(h->N, qd_k_candidates<NN><<<g1, dim3(QD_CAND_BLOCK), shm, s>>>(env_ids, base, h->R, h->params, h->state, h->recs));
         QD_HIP(hipGetLastError());
         int rc = qd_launch_ground(h, env_ids, base, cnt, s);
@@ -333,7 +338,7 @@ extern "C" int qd_time_candidates_kernel(qd_handle* h, int iters, float* mean_ms
     const int cnt = h->chunk < h->B ? h->chunk : h->B;
     const QdLayout& L = h->L;
     const size_t shm = sizeof(double) * (L.size + L.s_size) + (size_t)QD_K * QD_CAND_BLOCK * (sizeof(double) + sizeof(uint16_t));
-    dim3 g1((h->P + QD_CAND_BLOCK - 1) / QD_CAND_BLOCK, h->C, cnt);
+    dim3 g1(qd_cand_blocks(h->R), h->C, cnt);
     QD_HIP(hipEventRecord(a, s));
     for (int i = 0; i < iters; ++i) {
         QD_DISPATCH_N(h->N, qd_k_candidates<NN><<<g1, dim3(QD_CAND_BLOCK), shm, s>>>(nullptr, 0, h->R, h->params, h->state, h->recs));

@@ -26,6 +26,7 @@
 //   cgd      G*V   negative gate/barrier -> dot/sensor matrix (a6)
 //   cbg      nb*G  barrier-gate cross capacitance (positive)  (a10)
 //   ufac     N*N   upper U with cdd_inv[:N,:N] = U U^T        (k-best search)
+//   uinv     N     1 / U[i][i]                                 (k-best search)
 //   alpha    nb    barrier lever arms                         (a10)
 //   origin   G     virtual gate origin                        (a5)
 //   vopt     G     optimal physical gate voltages             (a21)
@@ -34,7 +35,7 @@
 //   tc_base, gamma, window, spare
 struct QdLayout {
     int N, G, nb, V;
-    int cdd_inv, cgd, cbg, ufac, alpha, origin, vopt, vbopt, pmin, pmax, bmin, bmax, scal, size;
+    int cdd_inv, cgd, cbg, ufac, uinv, alpha, origin, vopt, vbopt, pmin, pmax, bmin, bmax, scal, size;
     // STATE block (float64, mutable): vgm G*G, gate_v N, barrier_v nb, gate_gt N,
     // barrier_gt nb, sensor_gt 1, kal_mean N*N, kal_var N*N
     int s_vgm, s_gate_v, s_barrier_v, s_gate_gt, s_barrier_gt, s_sensor_gt, s_kmean, s_kvar, s_size;
@@ -48,6 +49,7 @@ QD_HD QdLayout qd_layout(int N) {
     L.cgd = o;     o += L.G * L.V;
     L.cbg = o;     o += L.nb * L.G;
     L.ufac = o;    o += N * N;
+    L.uinv = o;    o += N;
     L.alpha = o;   o += L.nb;
     L.origin = o;  o += L.G;
     L.vopt = o;    o += L.G;

@@ -82,7 +82,14 @@ qd_k_candidates(const int* __restrict__ env_ids, int env_base, int R, const doub
     const int e = env_ids ? env_ids[env_base + slot] : env_base + slot;
     const int ch = blockIdx.y;
     const int P = R * R;
-    const int p = blockIdx.x * QD_CAND_BLOCK + threadIdx.x;
+    // each wave works on an 8x8 pixel tile (not a 64x1 row): neighbouring pixels in BOTH sweep
+    // directions have nearly the same search tree, so the lanes of a wave diverge less
+    const int tiles_x = (R + 7) >> 3;
+    const int tile = blockIdx.x * (QD_CAND_BLOCK / 64) + (threadIdx.x >> 6);
+    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    const int x = tx * 8 + (threadIdx.x & 7), y = ty * 8 + ((threadIdx.x >> 3) & 7);
+    const bool inside = x < R && y < R;
+    const int p = y * R + x;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     double* spar = (double*)smem_raw;                         // L.size
@@ -92,8 +99,7 @@ qd_k_candidates(const int* __restrict__ env_ids, int env_base, int R, const doub
     for (int i = threadIdx.x; i < L.size; i += QD_CAND_BLOCK) spar[i] = params[(size_t)e * L.size + i];
     for (int i = threadIdx.x; i < L.s_size; i += QD_CAND_BLOCK) sst[i] = state[(size_t)e * L.s_size + i];
     __syncthreads();
-    if (p >= P) return;
-    const int y = p / R, x = p - y * R;
+    if (!inside) return;
     double v_ext[V], vpp[G], ncont[N], tc[NB];
     qd_pixel_front<N>(spar, sst, ch, R, x, y, v_ext, vpp, ncont, tc);
     int32_t fl[N];

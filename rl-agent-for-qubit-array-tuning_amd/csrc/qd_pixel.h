@@ -137,6 +137,7 @@ template <int N>
 struct QdSearch {
     const double* A; int lda;        // cdd_inv (row-major, lda = G)
     const double* U;                 // N*N row-major upper factor
+    const double* uinv;              // 1/U[i][i]
     double fl[N], vdash[N], m[N], g[N], tail[N];
     double dm[N], dv[N];             // current path: c - m, c - v'
     double Em;
@@ -145,7 +146,7 @@ struct QdSearch {
     int count;
     double lim;                      // prune when (partial + tail) > lim   (relative to Em)
     unsigned idx;
-    unsigned long long nodes, leaves, inserts;   // statistics (host harness only)
+    unsigned long long nodes, leaves, inserts, shifts;   // statistics (host harness only)
 };
 
 template <int N>
@@ -172,6 +173,9 @@ QD_HD void qd_search_insert(QdSearch<N>& S, double E, unsigned idx) {
         if (!(E < ep || (E == ep && idx < ip))) break;
         S.e[pos * S.es] = ep; S.id[pos * S.is] = (uint16_t)ip;
         --pos;
+#ifndef __HIP_DEVICE_COMPILE__
+        S.shifts++;
+#endif
     }
     S.e[pos * S.es] = E; S.id[pos * S.is] = (uint16_t)idx;
     qd_search_set_bound(S);
@@ -190,38 +194,38 @@ struct QdLevel {
 #pragma unroll
         for (int j = 0; j < L; ++j) s = fma(S.U[j * N + L], S.dm[j], s);
         const double uLL = S.U[L * N + L];
-        const double base = S.fl[L] - S.m[L];              // c - m for delta = 0
+        const double flL = S.fl[L];
+        const double base = flL - S.m[L];                  // c - m for delta = 0
         const double gL = S.g[L];
-        // increment f(k) = t^2 + g (c-m) of the four choices delta = k-1
-        double f0, f1, f2, f3;
-        { const double x = base - 1.0, t = fma(uLL, x, s); f0 = fma(t, t, gL * x); }
-        { const double x = base,       t = fma(uLL, x, s); f1 = fma(t, t, gL * x); }
-        { const double x = base + 1.0, t = fma(uLL, x, s); f2 = fma(t, t, gL * x); }
-        { const double x = base + 2.0, t = fma(uLL, x, s); f3 = fma(t, t, gL * x); }
-        int k0 = 0, k1 = 1, k2 = 2, k3 = 3;
-#define QD_CSWAP(i, j)                                                             \
-        if (f##j < f##i) { double tf = f##i; f##i = f##j; f##j = tf; int tk = k##i; k##i = k##j; k##j = tk; }
-        QD_CSWAP(0, 1) QD_CSWAP(2, 3) QD_CSWAP(0, 2) QD_CSWAP(1, 3) QD_CSWAP(1, 2)
-#undef QD_CSWAP
-        // only the packed visiting order stays live across the recursion; the increment of
-        // the visited choice is recomputed (same expression, same bits) to save registers
-        const unsigned order = (unsigned)k0 | ((unsigned)k1 << 2) | ((unsigned)k2 << 4) | ((unsigned)k3 << 6);
+        // The increment f(k) = (u x + s)^2 + g x, x = base + (k-1), is a convex parabola in k, so
+        // visiting k in order of distance from its real minimiser k* (Schnorr-Euchner zig-zag)
+        // visits the choices in increasing f; the first one that fails the bound ends the node.
+        const double ui = S.uinv[L];
+        const double kstar = (fma(-s, ui, -(0.5 * gL) * (ui * ui)) - base) + 1.0;
+        const int kmin = (flL > 0.0) ? 0 : 1;              // delta = -1 would give c < 0
+        double kc = rint(kstar);
+        kc = fmin(fmax(kc, (double)kmin), 3.0);
+        if (!(kc == kc)) kc = (double)kmin;                // NaN guard
+        int k = (int)kc, lo = k - 1, hi = k + 1;
         const unsigned sh = 2u * (unsigned)(N - 1 - L);
+        const double tl = S.tail[L];
         // ONE call site per level (a 4x unrolled visit would inline 4^N leaves)
 #pragma unroll 1
         for (int r = 0; r < 4; ++r) {
-            const int kr = (int)((order >> (2 * r)) & 3u);
-            const double flL = S.fl[L];
-            if (kr == 0 && !(flL > 0.0)) continue;           // delta = -1 would give c < 0
-            const double c = flL + (double)(kr - 1);
-            const double x = (flL - S.m[L]) + (double)(kr - 1);
-            const double t = fma(S.U[L * N + L], x, s);
-            const double pn = partial + fma(t, t, S.g[L] * x);
-            if (pn + S.tail[L] > S.lim) return;              // choices are in increasing f
+            const double x = base + (double)(k - 1);
+            const double t = fma(uLL, x, s);
+            const double pn = partial + fma(t, t, gL * x);
+            if (pn + tl > S.lim) return;
             S.dm[L] = x;
-            S.dv[L] = c - S.vdash[L];
-            S.idx = (S.idx & ~(3u << sh)) | ((unsigned)kr << sh);
+            S.dv[L] = (flL + (double)(k - 1)) - S.vdash[L];
+            S.idx = (S.idx & ~(3u << sh)) | ((unsigned)k << sh);
             QdLevel<N, L + 1>::run(S, pn);
+            const bool can_lo = lo >= kmin, can_hi = hi <= 3;
+            if (!can_lo && !can_hi) return;
+            const bool take_lo = can_lo && (!can_hi || (kstar - (double)lo) <= ((double)hi - kstar));
+            k = take_lo ? lo : hi;
+            lo -= take_lo ? 1 : 0;
+            hi += take_lo ? 0 : 1;
         }
     }
 };
@@ -250,7 +254,7 @@ QD_HD int qd_candidates(const double* par, const double* vpp, const double* ncon
                         unsigned long long* stats = nullptr) {
     const QdLayout L = qd_layout(N);
     QdSearch<N> S;
-    S.A = par + L.cdd_inv; S.lda = N + 1; S.U = par + L.ufac;
+    S.A = par + L.cdd_inv; S.lda = N + 1; S.U = par + L.ufac; S.uinv = par + L.uinv;
     bool shifted = false;
 #pragma unroll
     for (int i = 0; i < N; ++i) {
@@ -284,10 +288,10 @@ QD_HD int qd_candidates(const double* par, const double* vpp, const double* ncon
     }
     S.e = e; S.es = es; S.id = id; S.is = is;
     S.count = 0; S.lim = INFINITY; S.idx = 0;
-    S.nodes = S.leaves = S.inserts = 0;
+    S.nodes = S.leaves = S.inserts = S.shifts = 0;
     QdLevel<N, 0>::run(S, 0.0);
 #ifndef __HIP_DEVICE_COMPILE__
-    if (stats) { stats[0] += S.nodes; stats[1] += S.leaves; stats[2] += S.inserts; }
+    if (stats) { stats[0] += S.nodes; stats[1] += S.leaves; stats[2] += S.inserts; stats[3] += S.shifts; }
 #endif
     return S.count;
 }

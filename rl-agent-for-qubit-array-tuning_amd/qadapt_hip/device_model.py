@@ -237,6 +237,7 @@ class DeviceSampler:
         Lr = np.linalg.cholesky(A[:, ::-1, ::-1])
         U = Lr[:, ::-1, ::-1]
         P[:, L.ufac:L.ufac + N * N] = U.reshape(n, -1)
+        P[:, L.uinv:L.uinv + N] = 1.0 / U[:, np.arange(N), np.arange(N)]
         P[:, L.alpha:L.alpha + nb] = a["alpha"]
         origin = np.concatenate([a["offset"], np.zeros((n, 1))], axis=1)
         P[:, L.origin:L.origin + G] = origin

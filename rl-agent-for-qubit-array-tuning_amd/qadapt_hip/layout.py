@@ -14,6 +14,7 @@ class Layout:
     cgd: int
     cbg: int
     ufac: int
+    uinv: int
     alpha: int
     origin: int
     vopt: int
@@ -39,7 +40,7 @@ def layout(N: int) -> Layout:
     G, nb, V = N + 1, N - 1, 2 * N
     o = 0
     f = {}
-    for name, n in (("cdd_inv", G * G), ("cgd", G * V), ("cbg", nb * G), ("ufac", N * N),
+    for name, n in (("cdd_inv", G * G), ("cgd", G * V), ("cbg", nb * G), ("ufac", N * N), ("uinv", N),
                     ("alpha", nb), ("origin", G), ("vopt", G), ("vbopt", nb), ("pmin", N),
                     ("pmax", N), ("bmin", nb), ("bmax", nb), ("scal", 4)):
         f[name] = o
@@ -54,7 +55,7 @@ def layout(N: int) -> Layout:
     return Layout(N=N, G=G, nb=nb, V=V, **f)
 
 
-LAYOUT_FIELDS = ["N", "G", "nb", "V", "cdd_inv", "cgd", "cbg", "ufac", "alpha", "origin", "vopt",
+LAYOUT_FIELDS = ["N", "G", "nb", "V", "cdd_inv", "cgd", "cbg", "ufac", "uinv", "alpha", "origin", "vopt",
                  "vbopt", "pmin", "pmax", "bmin", "bmax", "scal", "size", "s_vgm", "s_gate_v",
                  "s_barrier_v", "s_gate_gt", "s_barrier_gt", "s_sensor_gt", "s_kmean", "s_kvar",
                  "s_size"]

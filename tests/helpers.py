@@ -96,7 +96,7 @@ def host_front(N, par, st, ch, R, pix=None):
     par = np.ascontiguousarray(par); st = np.ascontiguousarray(st)
     states = np.zeros((P, 32, N), np.int32); floors = np.zeros((P, N), np.int32)
     vpp = np.zeros((P, N + 1)); tc = np.zeros((P, N - 1)); nv = np.zeros(P, np.int32)
-    stats = np.zeros(3, np.uint64)
+    stats = np.zeros(4, np.uint64)
     rc = h.qdh_front(N, _p(par, ctypes.c_double), _p(st, ctypes.c_double), ch, R, p0, p1,
                      _p(states, ctypes.c_int32), _p(floors, ctypes.c_int32), _p(vpp, ctypes.c_double),
                      _p(tc, ctypes.c_double), _p(nv, ctypes.c_int32), _p(stats, ctypes.c_uint64))

@@ -45,6 +45,6 @@ def test_search_prunes(capsys):
     eb = H.sample_blocks(N, [77])
     st = H.place(N, eb.state[0], "near", np.random.default_rng(1))
     got = H.host_front(N, eb.params[0], st, 3, R)
-    nodes, leaves, inserts = (got["stats"] / (R * R)).tolist()
+    nodes, leaves, inserts, shifts = (got["stats"] / (R * R)).tolist()
     print(f"N=8 search per pixel: nodes {nodes:.0f} leaves {leaves:.0f} inserts {inserts:.0f}")
     assert leaves < 4 ** 8 / 20
