@@ -39,7 +39,7 @@
 struct QdWaveLds {
     double coef[QD_NBMAX][64];      // H_ij of neighbour slot s of lane
     unsigned char nidx[QD_NBMAX][64];
-    double buf[64];                 // publish buffer for per-component reductions
+    double buf[66];                 // publish buffer for per-component reductions; buf[64] == 0.0 (neutral slot)
     double al[64], be[64];          // T: alpha_r / beta_r at the r-th member lane
     double rd[64], lf[64], yv[64];  // inverse iteration: 1/d_i, l_i, y_i at member slots
     double ib[64];                  // 1/beta_r at the r-th member lane (pass-2 replay)
@@ -85,13 +85,24 @@ __device__ __forceinline__ int qd_wave_max_int(int v) {
 // per-component (segment) reductions through the LDS publish buffer.  `seg` is
 // the member mask (bit b = lane b of my half), hb = 0 or 32, smax = wave-wide
 // max member count.  Summation runs over members in ascending lane order, so
-// every member gets bit-identical results.
-__device__ __forceinline__ double qd_seg_sum(double v, unsigned seg, int smax, volatile double* buf, int hb) {
+// every member gets bit-identical results.  The first 8 member slots are kept as
+// register-resident LDS indices (`QdMembers`); slots beyond the member count
+// point at the neutral element buf[64] == 0.0, so the common case (components of
+// <= 8 states) is 8 independent LDS reads with no predication.
+struct QdMembers {
+    int idx[8];          // LDS index (into buf) of member i, or 64 (neutral) if i >= size
+    unsigned rest;       // members beyond the first 8
+    int nrest_max;       // wave-wide max count of such members
+};
+
+__device__ __forceinline__ double qd_seg_sum(double v, const QdMembers& M, volatile double* buf, int hb) {
     buf[threadIdx.x & 63] = v;
     __builtin_amdgcn_wave_barrier();
     double acc = 0.0;
-    unsigned mm = seg;
-    for (int it = 0; it < smax; ++it) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc += buf[M.idx[i]];
+    unsigned mm = M.rest;
+    for (int it = 0; it < M.nrest_max; ++it) {
         if (mm) { int b = __builtin_ctz(mm); mm &= mm - 1; acc += buf[hb + b]; }
     }
     __builtin_amdgcn_wave_barrier();
@@ -249,6 +260,17 @@ __device__ void qd_ground_pixel(const double* __restrict__ A, const QdPixelRec* 
     const int ssz = __popc(seg);
     const int r = __popc(seg & lt);                        // my index inside the component
     const int smax = qd_wave_max_int(ssz);
+    QdMembers MB;
+    {
+        unsigned mm = seg;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            MB.idx[i] = mm ? hb + __builtin_ctz(mm) : 64;
+            mm &= mm - 1;
+        }
+        MB.rest = mm;
+        MB.nrest_max = smax > 8 ? smax - 8 : 0;
+    }
 
     // ---- 4. Gershgorin pruning ---------------------------------------------
     double radius = 0.0;
@@ -272,9 +294,9 @@ __device__ void qd_ground_pixel(const double* __restrict__ A, const QdPixelRec* 
             const double qj = __shfl(q, (int)W.nidx[s][lane], 32);
             w = fma(W.coef[s][lane], qj, w);
         }
-        const double a = qd_seg_sum(q * w, seg, smax, buf, hb);
+        const double a = qd_seg_sum(q * w, MB, buf, hb);
         w = w - a * q - bp * qp;
-        const double b2 = qd_seg_sum(w * w, seg, smax, buf, hb);
+        const double b2 = qd_seg_sum(w * w, MB, buf, hb);
         double b = 0.0, ib = 0.0;
         if (b2 > 0.0) qd_sqrt_rsqrt(b2, b, ib);
         if (!done) {
@@ -456,7 +478,7 @@ __device__ void qd_ground_pixel(const double* __restrict__ A, const QdPixelRec* 
         }
     }
     if (solve) {
-        const double nx = qd_seg_sum(x * x, seg, smax, buf, hb);
+        const double nx = qd_seg_sum(x * x, MB, buf, hb);
         x = x * (1.0 / sqrt(nx));
     }
 

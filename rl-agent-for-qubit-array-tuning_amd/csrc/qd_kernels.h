@@ -138,6 +138,7 @@ qd_k_ground(const int* __restrict__ env_ids, int env_base, int R, const double* 
     const double* par = params + (size_t)e * L.size;
     for (int i = threadIdx.x; i < G * G; i += QD_GS_BLOCK) sA[i] = par[L.cdd_inv + i];
     if (threadIdx.x == 0) sA[G * G] = par[L.scal + 1];       // gamma
+    if (threadIdx.x < QD_GS_BLOCK / 64) { sW[threadIdx.x].buf[64] = 0.0; sW[threadIdx.x].buf[65] = 0.0; }
     __syncthreads();
     const int half = threadIdx.x >> 5;                       // 0..7
     QdWaveLds& W = sW[threadIdx.x >> 6];

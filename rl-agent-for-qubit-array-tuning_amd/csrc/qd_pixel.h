@@ -140,6 +140,7 @@ struct QdSearch {
     const double* uinv;              // 1/U[i][i]
     double fl[N], vdash[N], m[N], g[N], tail[N];
     double dm[N], dv[N];             // current path: c - m, c - v'
+    double pre1[N], pre2[N];         // canonical row sums over dots 0..A and 0..B of the current path
     double Em;
     double* e; int es;               // energies, stride
     uint16_t* id; int is;            // indices, stride
@@ -184,6 +185,13 @@ QD_HD void qd_search_insert(QdSearch<N>& S, double E, unsigned idx) {
 #endif
 }
 
+// split points of the shared canonical row sums: dots 0..A, A+1..B, and B+1..N-1 at the leaf
+template <int N>
+struct QdSplit {
+    static constexpr int B = N - 3;                       // leaf finishes the last two dots
+    static constexpr int A = (B - 3 >= 0) ? B - 3 : -1;
+};
+
 template <int N, int L>
 struct QdLevel {
     static QD_HD void run(QdSearch<N>& S, double partial) {
@@ -219,6 +227,26 @@ struct QdLevel {
             S.dm[L] = x;
             S.dv[L] = (flL + (double)(k - 1)) - S.vdash[L];
             S.idx = (S.idx & ~(3u << sh)) | ((unsigned)k << sh);
+            // canonical energy rows t_i = fma-chain over j = 0..N-1 of A[i][j] dv[j]: the part of the
+            // chain that only involves dots already fixed is shared by the whole sub-tree
+            if constexpr (L == QdSplit<N>::A) {
+#pragma unroll
+                for (int i = 0; i < N; ++i) {
+                    double acc = 0.0;
+#pragma unroll
+                    for (int j = 0; j <= QdSplit<N>::A; ++j) acc = fma(S.A[i * S.lda + j], S.dv[j], acc);
+                    S.pre1[i] = acc;
+                }
+            }
+            if constexpr (L == QdSplit<N>::B) {
+#pragma unroll
+                for (int i = 0; i < N; ++i) {
+                    double acc = (QdSplit<N>::A >= 0) ? S.pre1[i] : 0.0;
+#pragma unroll
+                    for (int j = QdSplit<N>::A + 1; j <= QdSplit<N>::B; ++j) acc = fma(S.A[i * S.lda + j], S.dv[j], acc);
+                    S.pre2[i] = acc;
+                }
+            }
             QdLevel<N, L + 1>::run(S, pn);
             const bool can_lo = lo >= kmin, can_hi = hi <= 3;
             if (!can_lo && !can_hi) return;
@@ -239,7 +267,9 @@ struct QdLevel<N, N> {
         double E = 0.0;
 #pragma unroll
         for (int i = 0; i < N; ++i) {
-            double t = qd_dotN<N>(S.A + i * S.lda, S.dv);
+            double t = (QdSplit<N>::B >= 0) ? S.pre2[i] : 0.0;
+#pragma unroll
+            for (int j = QdSplit<N>::B + 1; j < N; ++j) t = fma(S.A[i * S.lda + j], S.dv[j], t);
             E = fma(S.dv[i], t, E);
         }
         qd_search_insert(S, E, S.idx);
