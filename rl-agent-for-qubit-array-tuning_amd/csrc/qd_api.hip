@@ -217,7 +217,7 @@ extern "C" int qd_observe(qd_handle* h, const int32_t* env_ids, int n, void* str
     for (int base = 0; base < n; base += h->chunk) {
         const int cnt = (n - base < h->chunk) ? n - base : h->chunk;
         dim3 g1(qd_cand_blocks(h->R), h->C, cnt);
-        QD_DISPATCH_N(h->N, qd_k_candidates<NN><<<g1, dim3(QD_CAND_BLOCK), shm, s>>>(env_ids, base, h->R, h->params, h->state, h->recs));
+        QD_DISPATCH_N(h->N, qd_k_candidates<NN><<<g1, dim3(QD_CAND_BLOCK), shm, s>>>(env_ids, base, h->R, h->params, h->state, h->recs, (h->cfg.flags & QD_FLAG_VALIDATE) ? 1 : 0));
         QD_HIP(hipGetLastError());
         int rc = qd_launch_ground(h, env_ids, base, cnt, s);
         if (rc) return rc;
@@ -341,7 +341,7 @@ extern "C" int qd_time_candidates_kernel(qd_handle* h, int iters, float* mean_ms
     dim3 g1(qd_cand_blocks(h->R), h->C, cnt);
     QD_HIP(hipEventRecord(a, s));
     for (int i = 0; i < iters; ++i) {
-        QD_DISPATCH_N(h->N, qd_k_candidates<NN><<<g1, dim3(QD_CAND_BLOCK), shm, s>>>(nullptr, 0, h->R, h->params, h->state, h->recs));
+        QD_DISPATCH_N(h->N, qd_k_candidates<NN><<<g1, dim3(QD_CAND_BLOCK), shm, s>>>(nullptr, 0, h->R, h->params, h->state, h->recs, (h->cfg.flags & QD_FLAG_VALIDATE) ? 1 : 0));
     }
     QD_HIP(hipGetLastError());
     QD_HIP(hipEventRecord(b, s));

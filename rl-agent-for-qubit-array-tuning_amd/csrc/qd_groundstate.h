@@ -485,8 +485,13 @@ __device__ void qd_ground_pixel(const double* __restrict__ A, const QdPixelRec* 
     // ---- 8. pick the lowest component, expectation occupations --------------
     const double mylam = active ? lam : INFINITY;
     const double best = qd_half_min(mylam);
-    // tie between components: lowest root lane wins (deterministic)
-    const unsigned win = qd_half_ballot(mylam == best);
+    // tie between components (exactly equal energies): the state with the lowest candidate
+    // index wins -- the reference order puts it first -- independent of the buffer order
+    unsigned key = (mylam == best) ? (valid ? code : 0xFFFFFFFEu) : 0xFFFFFFFFu;
+    unsigned kmin = key;
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) { const unsigned t = (unsigned)__shfl_xor((int)kmin, o, 32); kmin = t < kmin ? t : kmin; }
+    const unsigned win = qd_half_ballot(key == kmin);
     const int wroot = __builtin_ctz(win);
     const unsigned wseg = __shfl(seg, wroot, 32);
     const double p = ((wseg >> m) & 1u) ? x * x : 0.0;

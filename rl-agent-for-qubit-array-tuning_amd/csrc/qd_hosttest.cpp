@@ -17,7 +17,7 @@ static int run_front(const double* par, const double* st, int ch, int R, int p0,
         double v_ext[V], vpp[G], ncont[N], tc[NB > 0 ? NB : 1];
         qd_pixel_front<N>(par, st, ch, R, x, y, v_ext, vpp, ncont, tc);
         double e[QD_K]; uint16_t id[QD_K]; int32_t fl[N];
-        int nv = qd_candidates<N>(par, vpp, ncont, e, 1, id, 1, fl, stats);
+        int nv = qd_candidates<N>(par, vpp, ncont, e, 1, id, 1, fl, true, stats);
         static const int DELTA[4] = {-1, 0, 1, 2};
         for (int m = 0; m < QD_K; ++m)
             for (int i = 0; i < N; ++i) {

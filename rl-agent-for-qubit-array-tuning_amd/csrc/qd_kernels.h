@@ -75,7 +75,7 @@ __global__ void qd_k_actions(int B, const double* __restrict__ params, double* _
 template <int N>
 __global__ void __launch_bounds__(QD_CAND_BLOCK)
 qd_k_candidates(const int* __restrict__ env_ids, int env_base, int R, const double* __restrict__ params,
-                const double* __restrict__ state, QdPixelRec* __restrict__ recs) {
+                const double* __restrict__ state, QdPixelRec* __restrict__ recs, int sort_output) {
     constexpr int G = N + 1, NB = N - 1, V = 2 * N;
     const QdLayout L = qd_layout(N);
     const int slot = blockIdx.z;
@@ -104,7 +104,7 @@ qd_k_candidates(const int* __restrict__ env_ids, int env_base, int R, const doub
     qd_pixel_front<N>(spar, sst, ch, R, x, y, v_ext, vpp, ncont, tc);
     int32_t fl[N];
     const int nv = qd_candidates<N>(spar, vpp, ncont, se + threadIdx.x, QD_CAND_BLOCK,
-                                    sid + threadIdx.x, QD_CAND_BLOCK, fl);
+                                    sid + threadIdx.x, QD_CAND_BLOCK, fl, sort_output != 0);
     QdPixelRec* rec = recs + ((size_t)slot * (N - 1) + ch) * P + p;
 #pragma unroll
     for (int m = 0; m < QD_K; ++m) rec->idx[m] = m < nv ? sid[m * QD_CAND_BLOCK + threadIdx.x] : 0;

@@ -145,44 +145,83 @@ struct QdSearch {
     double* e; int es;               // energies, stride
     uint16_t* id; int is;            // indices, stride
     int count;
+    double gE[4]; unsigned gI[4]; int gS[4];    // per-group maxima of the kept buffer
+    double maxE; unsigned maxI; int maxS, maxG;  // overall maximum (the 32nd best)
     double lim;                      // prune when (partial + tail) > lim   (relative to Em)
     unsigned idx;
     unsigned long long nodes, leaves, inserts, shifts;   // statistics (host harness only)
 };
 
+// The kept set lives in caller-provided strided storage (LDS on the GPU) as an UNSORTED buffer
+// split into 4 groups of 8 slots; the lexicographic (E, idx) maximum of each group is cached in
+// registers.  Replacing the overall maximum costs one write + an 8-slot rescan (independent
+// reads) instead of a chain of dependent compare-and-shift steps.  qd_search_sort() orders the
+// final list when the caller wants the reference order.
+template <int N>
+QD_HD bool qd_lex_less(double ea, unsigned ia, double eb, unsigned ib) {
+    return ea < eb || (ea == eb && ia < ib);
+}
+
+template <int N>
+QD_HD void qd_search_rescan_group(QdSearch<N>& S, int g) {
+    double me = -INFINITY; unsigned mi = 0; int ms = g * 8;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const int sl = g * 8 + t;
+        const double e = S.e[sl * S.es]; const unsigned i = S.id[sl * S.is];
+        if (t == 0 || qd_lex_less<N>(me, mi, e, i)) { me = e; mi = i; ms = sl; }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) if (j == g) { S.gE[j] = me; S.gI[j] = mi; S.gS[j] = ms; }
+}
+
 template <int N>
 QD_HD void qd_search_set_bound(QdSearch<N>& S) {
-    if (S.count == QD_K) {
-        const double bound = S.e[(QD_K - 1) * S.es];
-        S.lim = (bound - S.Em) + ((fabs(bound) + fabs(S.Em)) * 1e-11 + 1e-300);
-    }
+    // overall maximum = lexicographic max of the 4 group maxima
+    int g = 0; double bound = S.gE[0]; unsigned bi = S.gI[0]; int bs = S.gS[0];
+#pragma unroll
+    for (int j = 1; j < 4; ++j)
+        if (qd_lex_less<N>(bound, bi, S.gE[j], S.gI[j])) { bound = S.gE[j]; bi = S.gI[j]; bs = S.gS[j]; g = j; }
+    S.maxE = bound; S.maxI = bi; S.maxS = bs; S.maxG = g;
+    S.lim = (bound - S.Em) + ((fabs(bound) + fabs(S.Em)) * 1e-11 + 1e-300);
 }
 
 template <int N>
 QD_HD void qd_search_insert(QdSearch<N>& S, double E, unsigned idx) {
     if (!(E < INFINITY)) return;                          // inf / NaN: treated as invalid
-    int pos;
-    if (S.count == QD_K) {
-        double el = S.e[(QD_K - 1) * S.es]; unsigned il = S.id[(QD_K - 1) * S.is];
-        if (!(E < el || (E == el && idx < il))) return;
-        pos = QD_K - 1;
-    } else {
-        pos = S.count; S.count++;
-    }
-    while (pos > 0) {
-        double ep = S.e[(pos - 1) * S.es]; unsigned ip = S.id[(pos - 1) * S.is];
-        if (!(E < ep || (E == ep && idx < ip))) break;
-        S.e[pos * S.es] = ep; S.id[pos * S.is] = (uint16_t)ip;
-        --pos;
-#ifndef __HIP_DEVICE_COMPILE__
-        S.shifts++;
-#endif
-    }
-    S.e[pos * S.es] = E; S.id[pos * S.is] = (uint16_t)idx;
-    qd_search_set_bound(S);
 #ifndef __HIP_DEVICE_COMPILE__
     S.inserts++;
 #endif
+    if (S.count < QD_K) {
+        S.e[S.count * S.es] = E; S.id[S.count * S.is] = (uint16_t)idx;
+        S.count++;
+        if (S.count == QD_K) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) qd_search_rescan_group(S, g);
+            qd_search_set_bound(S);
+        }
+        return;
+    }
+    if (!qd_lex_less<N>(E, idx, S.maxE, S.maxI)) return;
+    S.e[S.maxS * S.es] = E; S.id[S.maxS * S.is] = (uint16_t)idx;
+    qd_search_rescan_group(S, S.maxG);
+    qd_search_set_bound(S);
+}
+
+// in-place insertion sort of the kept entries by (E, idx)
+template <int N>
+QD_HD void qd_search_sort(QdSearch<N>& S) {
+    for (int i = 1; i < S.count; ++i) {
+        const double E = S.e[i * S.es]; const unsigned idx = S.id[i * S.is];
+        int pos = i;
+        while (pos > 0) {
+            const double ep = S.e[(pos - 1) * S.es]; const unsigned ip = S.id[(pos - 1) * S.is];
+            if (!qd_lex_less<N>(E, idx, ep, ip)) break;
+            S.e[pos * S.es] = ep; S.id[pos * S.is] = (uint16_t)ip;
+            --pos;
+        }
+        S.e[pos * S.es] = E; S.id[pos * S.is] = (uint16_t)idx;
+    }
 }
 
 // split points of the shared canonical row sums: dots 0..A, A+1..B, and B+1..N-1 at the leaf
@@ -276,11 +315,11 @@ struct QdLevel<N, N> {
     }
 };
 
-// Returns the number of valid candidates found (<= 32).  e/id are filled in
-// order of increasing (E, idx).
+// Returns the number of valid candidates found (<= 32).  With sort_output the list is in the
+// reference order (increasing (E, idx)); otherwise it is the same SET in search order.
 template <int N>
 QD_HD int qd_candidates(const double* par, const double* vpp, const double* ncont,
-                        double* e, int es, uint16_t* id, int is, int32_t* fl_out,
+                        double* e, int es, uint16_t* id, int is, int32_t* fl_out, bool sort_output,
                         unsigned long long* stats = nullptr) {
     const QdLayout L = qd_layout(N);
     QdSearch<N> S;
@@ -320,6 +359,7 @@ QD_HD int qd_candidates(const double* par, const double* vpp, const double* ncon
     S.count = 0; S.lim = INFINITY; S.idx = 0;
     S.nodes = S.leaves = S.inserts = S.shifts = 0;
     QdLevel<N, 0>::run(S, 0.0);
+    if (sort_output) qd_search_sort(S);
 #ifndef __HIP_DEVICE_COMPILE__
     if (stats) { stats[0] += S.nodes; stats[1] += S.leaves; stats[2] += S.inserts; stats[3] += S.shifts; }
 #endif

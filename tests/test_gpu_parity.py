@@ -296,3 +296,29 @@ def test_multi_agent_wrapper_end_to_end_on_gpu(tmp_path):
     obs, infos = w.reset()
     assert obs["plunger_0"]["image"].shape == (R, R, 2)
     w.close()
+
+
+@pytest.mark.parametrize("N,R", [(4, 16), (8, 16)])
+def test_product_mode_equals_validate_mode(N, R):
+    """Without QD_FLAG_VALIDATE the candidate kernel hands the kept states to the ground-state
+    kernel in search order (unsorted); the physics must not depend on that order."""
+    import torch
+    from qadapt_hip.vec_env import VecQuantumDeviceEnv, SyntheticCapacitanceModel
+    B = 3
+    outs = []
+    for validate in (True, False):
+        env = VecQuantumDeviceEnv(B, num_dots=N, resolution=R, validate=validate, seed=31,
+                                  capacitance_model=SyntheticCapacitanceModel(2))
+        env.reset()
+        st, steps = env.get_state()
+        rng = np.random.default_rng(9)
+        for e in range(B):
+            st[e] = H.place(N, st[e], ("near", "mid", "near")[e], rng)
+        env.set_state(st, steps)
+        from qadapt_hip import _lib
+        _lib.check(env._h, env._lib.qd_observe(env._h, None, 0, env._stream()), "qd_observe")
+        raw, plohi = env.raw()
+        outs.append((raw, env.global_image.cpu().numpy().copy()))
+        env.close()
+    assert np.allclose(outs[0][0], outs[1][0], rtol=1e-9, atol=1e-12)
+    assert np.abs(outs[0][1] - outs[1][1]).max() <= 1e-6
