@@ -35,6 +35,14 @@ extern "C" {
 
 #define QD_FLAG_VALIDATE 1    /* keep per-pixel candidate records and occupations  */
 
+/* Stochastic stages.  The generators are counter-based Philox streams, so
+ * results are reproducible per (rng_seed, global env id, observation number, channel, pixel)
+ * but NOT comparable sample-by-sample with the reference's numpy global RNG. */
+#define QD_NOISE_SENSOR 1     /* white + telegraph noise on the sensor potential
+                                 (TunnelCoupledChargeSensed.py:354; qarray WhiteNoise/TelegraphNoise) */
+#define QD_NOISE_RADIAL 2     /* distance-dependent image noise / white-noise replacement
+                                 (qarray_base_class.py:444-493)                     */
+
 typedef struct qd_handle qd_handle;
 
 /* Mirrors the env_config.yaml / constructor knobs of QuantumDeviceEnv
@@ -47,7 +55,7 @@ typedef struct qd_config {
     int32_t max_steps;            /* truncation horizon (simulator.max_steps)     */
     int32_t env_chunk;            /* envs per scratch chunk, 0 = choose            */
     int32_t flags;                /* QD_FLAG_*                                     */
-    int32_t reserved;
+    int32_t noise_flags;          /* QD_NOISE_* (0 = deterministic parity mode)           */
     double gate_ramp_start;       /* reward.gate_ramp_start                        */
     double gate_quadratic_start;  /* reward.gate_quadratic_start                   */
     double barrier_ramp_start;    /* reward.barrier_ramp_start                     */
@@ -56,14 +64,16 @@ typedef struct qd_config {
     double kalman_prior_mean_nnn; /* env.py:786                                    */
     double kalman_variance_threshold; /* capacitance_model.variance_threshold     */
     double kalman_process_noise;  /* capacitance_model.process_noise               */
+    uint64_t rng_seed;            /* Philox key for the stochastic stages          */
+    int64_t env_id_offset;        /* global id of env 0 (multi-GPU shards)         */
 } qd_config;
 
 /* Sizes (in float64 elements) of the per-env parameter and state blocks whose
  * layout is documented in csrc/qd_common.h (mirrored by qadapt_hip/layout.py). */
 int qd_param_block_doubles(int n_dot);
 int qd_state_block_doubles(int n_dot);
-/* Writes the 28 layout integers (see qadapt_hip/layout.py LAYOUT_FIELDS). */
-int qd_layout_query(int n_dot, int32_t* out28);
+/* Writes the 29 layout integers (see qadapt_hip/layout.py LAYOUT_FIELDS). */
+int qd_layout_query(int n_dot, int32_t* out29);
 
 /* QuantumDeviceEnv.__init__ (env.py:38-132): allocates device state for B envs
  * on GPU `device`; Kalman filters start at their priors (env.py:779-787). */

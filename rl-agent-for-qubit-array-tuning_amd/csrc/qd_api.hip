@@ -21,6 +21,8 @@ struct qd_handle {
     size_t recs_envs;                       // envs the recs buffer holds
     int* rec_env_of_slot;                   // validate mode: recs are stored per env id
     float *gimg, *pimg, *bimg, *volt;
+    unsigned long long* tel; int tel_words;
+    unsigned long long obs_serial;
     char err[512];
 };
 
@@ -84,6 +86,11 @@ extern "C" int qd_create(const qd_config* cfg, int device, qd_handle** out) {
     QD_HIP(hipMalloc(&h->zraw, sizeof(double) * (size_t)h->B * h->C * h->P));
     QD_HIP(hipMalloc(&h->plohi, sizeof(double) * 2 * (size_t)h->B));
     QD_HIP(hipMalloc(&h->recs, per_env_rec * h->recs_envs));
+    h->tel_words = (h->P + 63) / 64;
+    if (cfg->noise_flags & QD_NOISE_SENSOR) {
+        QD_HIP(hipMalloc(&h->tel, sizeof(unsigned long long) * (size_t)h->B * h->C * h->tel_words));
+        QD_HIP(hipMemset(h->tel, 0, sizeof(unsigned long long) * (size_t)h->B * h->C * h->tel_words));
+    }
     if (cfg->flags & QD_FLAG_VALIDATE)
         QD_HIP(hipMalloc(&h->occ, sizeof(double) * (size_t)h->B * h->C * h->P * h->N));
     QD_HIP(hipMemset(h->params, 0, sizeof(double) * (size_t)h->B * h->L.size));
@@ -119,7 +126,7 @@ extern "C" int qd_destroy(qd_handle* h) {
     if (!h) return QD_ERR_ARG;
     hipSetDevice(h->device);
     hipFree(h->params); hipFree(h->state); hipFree(h->steps); hipFree(h->zraw); hipFree(h->plohi);
-    hipFree(h->recs); if (h->occ) hipFree(h->occ);
+    hipFree(h->recs); if (h->occ) hipFree(h->occ); if (h->tel) hipFree(h->tel);
     delete h;
     return QD_OK;
 }
@@ -197,10 +204,20 @@ static int qd_cand_blocks(int R) {
     return (tiles + per_block - 1) / per_block;
 }
 
+static QdNoiseCfg qd_noise_cfg(const qd_handle* h) {
+    QdNoiseCfg nz;
+    nz.flags = h->cfg.noise_flags;
+    nz.seed = (uint32_t)(h->cfg.rng_seed ^ (h->cfg.rng_seed >> 32));
+    nz.env_off = (uint32_t)h->cfg.env_id_offset;
+    nz.ser_lo = (uint32_t)h->obs_serial; nz.ser_hi = (uint32_t)(h->obs_serial >> 32);
+    nz.tel = h->tel; nz.tel_words = h->tel_words;
+    return nz;
+}
+
 static int qd_launch_ground(qd_handle* h, const int32_t* env_ids, int base, int cnt, hipStream_t s) {
     dim3 g2((h->P + QD_GS_PPB - 1) / QD_GS_PPB, h->C, cnt);
     QD_DISPATCH_N(h->N, qd_k_ground<NN><<<g2, dim3(QD_GS_BLOCK), 0, s>>>(env_ids, base, h->R,
-                                            h->params, h->recs, h->zraw, h->occ));
+                                            h->params, h->recs, h->zraw, h->occ, h->state, qd_noise_cfg(h)));
     QD_HIP(hipGetLastError());
     return QD_OK;
 }
@@ -214,10 +231,16 @@ extern "C" int qd_observe(qd_handle* h, const int32_t* env_ids, int n, void* str
     if (n > h->B) return qd_fail(h, QD_ERR_ARG, "qd_observe: n > batch");
     const QdLayout& L = h->L;
     const size_t shm = sizeof(double) * (L.size + L.s_size) + (size_t)QD_K * QD_CAND_BLOCK * (sizeof(double) + sizeof(uint16_t));
+    h->obs_serial++;
+    if (h->cfg.noise_flags & QD_NOISE_SENSOR) {
+        const int nt = n * h->C;
+        qd_k_telegraph<<<dim3((nt + 63) / 64), dim3(64), 0, s>>>(env_ids, n, h->C, h->P, L.size, L.noise, h->params, h->tel, qd_noise_cfg(h));
+        QD_HIP(hipGetLastError());
+    }
     for (int base = 0; base < n; base += h->chunk) {
         const int cnt = (n - base < h->chunk) ? n - base : h->chunk;
         dim3 g1(qd_cand_blocks(h->R), h->C, cnt);
-        QD_DISPATCH_N(h->N, qd_k_candidates<NN><<<g1, dim3(QD_CAND_BLOCK), shm, s>>>(env_ids, base, h->R, h->params, h->state, h->recs, (h->cfg.flags & QD_FLAG_VALIDATE) ? 1 : 0));
+        QD_DISPATCH_N(h->N, qd_k_candidates<NN><<<g1, dim3(QD_CAND_BLOCK), shm, s>>>(env_ids, base, h->R, h->params, h->state, h->recs, (h->cfg.flags & QD_FLAG_VALIDATE) ? 1 : 0, h->cfg.noise_flags));
         QD_HIP(hipGetLastError());
         int rc = qd_launch_ground(h, env_ids, base, cnt, s);
         if (rc) return rc;
@@ -341,7 +364,7 @@ extern "C" int qd_time_candidates_kernel(qd_handle* h, int iters, float* mean_ms
     dim3 g1(qd_cand_blocks(h->R), h->C, cnt);
     QD_HIP(hipEventRecord(a, s));
     for (int i = 0; i < iters; ++i) {
-        QD_DISPATCH_N(h->N, qd_k_candidates<NN><<<g1, dim3(QD_CAND_BLOCK), shm, s>>>(nullptr, 0, h->R, h->params, h->state, h->recs, (h->cfg.flags & QD_FLAG_VALIDATE) ? 1 : 0));
+        QD_DISPATCH_N(h->N, qd_k_candidates<NN><<<g1, dim3(QD_CAND_BLOCK), shm, s>>>(nullptr, 0, h->R, h->params, h->state, h->recs, (h->cfg.flags & QD_FLAG_VALIDATE) ? 1 : 0, h->cfg.noise_flags));
     }
     QD_HIP(hipGetLastError());
     QD_HIP(hipEventRecord(b, s));

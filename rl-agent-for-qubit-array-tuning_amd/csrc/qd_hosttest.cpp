@@ -6,6 +6,7 @@
 // exists as HIP code).  Built by tests via csrc/Makefile target hosttest.
 #include <string.h>
 #include "qd_pixel.h"
+#include "qd_rng.h"
 
 template <int N>
 static int run_front(const double* par, const double* st, int ch, int R, int p0, int p1,
@@ -57,3 +58,15 @@ extern "C" void qdh_layout(int N, int* out) {
     memcpy(out, &L, sizeof(L));
 }
 extern "C" int qdh_layout_ints() { return (int)(sizeof(QdLayout) / sizeof(int)); }
+
+extern "C" void qdh_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t* out4) {
+    QdPhilox r = qd_philox4x32_10(c0, c1, c2, c3, k0, k1);
+    for (int i = 0; i < 4; ++i) out4[i] = r.v[i];
+}
+extern "C" void qdh_normals(uint32_t k0, uint32_t k1, int n, double* out) {
+    for (int i = 0; i < n; i += 2) {
+        QdPhilox r = qd_philox4x32_10((uint32_t)(i / 2), 7u, 0u, 0u, k0, k1);
+        double a, b; qd_normal2(r, a, b);
+        out[i] = a; if (i + 1 < n) out[i + 1] = b;
+    }
+}

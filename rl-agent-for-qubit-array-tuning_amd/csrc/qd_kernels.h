@@ -13,6 +13,7 @@
 //   zraw   [B][C][P] f64 raw sensor signal,  plohi [B][2] f64
 #pragma once
 #include "qd_groundstate.h"
+#include "qd_rng.h"
 
 #if defined(__HIPCC__)
 
@@ -68,6 +69,53 @@ __global__ void qd_k_actions(int B, const double* __restrict__ params, double* _
 }
 
 // ---------------------------------------------------------------------------
+// a16: stochastic stages.  flags = QD_NOISE_* (0: deterministic).
+// ---------------------------------------------------------------------------
+struct QdNoiseCfg {
+    int flags;
+    uint32_t seed, env_off, ser_lo, ser_hi;       // Philox key / counter words
+    const unsigned long long* tel;                // telegraph state bits [B][C][tel_words]
+    int tel_words;
+};
+
+// qarray_base_class.py:462-468: the whole channel image is replaced by white noise when either
+// swept gate is further than full_noise_distance from its ground truth.
+__device__ __forceinline__ bool qd_radial_replaced(const double* par, const double* st, const QdLayout& L, int ch, int flags) {
+    if (!(flags & 2)) return false;
+    const double full = par[L.noise + 6];
+    if (!(full > 0.0)) return false;
+    const double d1 = fabs(st[L.s_gate_v + ch] - st[L.s_gate_gt + ch]);
+    const double d2 = fabs(st[L.s_gate_v + ch + 1] - st[L.s_gate_gt + ch + 1]);
+    return d1 > full || d2 > full;
+}
+
+// Random telegraph process along the row-major raster of one (env, channel): two-state Markov
+// chain, P(0->1) = p01, P(1->0) = p10, started from its stationary distribution; bit p of the
+// output = state at pixel p.  One thread per (env, channel) -- the chain is serial by nature.
+__global__ void qd_k_telegraph(const int* __restrict__ env_ids, int n_env, int C, int P, int psize, int noise_off,
+                               const double* __restrict__ params, unsigned long long* __restrict__ tel, QdNoiseCfg nz) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_env * C) return;
+    const int slot = t / C, ch = t - slot * C;
+    const int e = env_ids ? env_ids[slot] : slot;
+    const double* par = params + (size_t)e * psize + noise_off;
+    const double p01 = par[1], p10 = par[2];
+    unsigned long long* out = tel + ((size_t)e * C + ch) * nz.tel_words;
+    const uint32_t k1 = nz.env_off + (uint32_t)e;
+    QdPhilox r = qd_philox4x32_10(0xFFFFFFFFu, (uint32_t)ch | (QD_RNG_TELEGRAPH << 16), nz.ser_lo, nz.ser_hi, nz.seed, k1);
+    const double pst = (p01 + p10 > 0.0) ? p01 / (p01 + p10) : 0.0;
+    int state = qd_u01(r.v[0], r.v[1]) < pst ? 1 : 0;
+    unsigned long long word = 0;
+    for (int p = 0; p < P; ++p) {
+        if ((p & 1) == 0) r = qd_philox4x32_10((uint32_t)(p >> 1), (uint32_t)ch | (QD_RNG_TELEGRAPH << 16), nz.ser_lo, nz.ser_hi, nz.seed, k1);
+        const double u = (p & 1) ? qd_u01(r.v[2], r.v[3]) : qd_u01(r.v[0], r.v[1]);
+        if (state == 0) { if (u < p01) state = 1; } else { if (u < p10) state = 0; }
+        word |= (unsigned long long)state << (p & 63);
+        if ((p & 63) == 63 || p == P - 1) { out[p >> 6] = word; word = 0; }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // a5/a8/a9/a10: one pixel per lane.  grid = (ceil(P/BLOCK), C, n_env).
 // ---------------------------------------------------------------------------
 #define QD_CAND_BLOCK 128
@@ -75,7 +123,7 @@ __global__ void qd_k_actions(int B, const double* __restrict__ params, double* _
 template <int N>
 __global__ void __launch_bounds__(QD_CAND_BLOCK)
 qd_k_candidates(const int* __restrict__ env_ids, int env_base, int R, const double* __restrict__ params,
-                const double* __restrict__ state, QdPixelRec* __restrict__ recs, int sort_output) {
+                const double* __restrict__ state, QdPixelRec* __restrict__ recs, int sort_output, int noise_flags) {
     constexpr int G = N + 1, NB = N - 1, V = 2 * N;
     const QdLayout L = qd_layout(N);
     const int slot = blockIdx.z;
@@ -100,6 +148,7 @@ qd_k_candidates(const int* __restrict__ env_ids, int env_base, int R, const doub
     for (int i = threadIdx.x; i < L.s_size; i += QD_CAND_BLOCK) sst[i] = state[(size_t)e * L.s_size + i];
     __syncthreads();
     if (!inside) return;
+    if (qd_radial_replaced(spar, sst, L, ch, noise_flags)) return;   // image will be pure noise: nothing to solve
     double v_ext[V], vpp[G], ncont[N], tc[NB];
     qd_pixel_front<N>(spar, sst, ch, R, x, y, v_ext, vpp, ncont, tc);
     int32_t fl[N];
@@ -126,7 +175,8 @@ qd_k_candidates(const int* __restrict__ env_ids, int env_base, int R, const doub
 template <int N>
 __global__ void __launch_bounds__(QD_GS_BLOCK)
 qd_k_ground(const int* __restrict__ env_ids, int env_base, int R, const double* __restrict__ params,
-            const QdPixelRec* __restrict__ recs, double* __restrict__ zraw, double* __restrict__ occ_out) {
+            const QdPixelRec* __restrict__ recs, double* __restrict__ zraw, double* __restrict__ occ_out,
+            const double* __restrict__ state, QdNoiseCfg nz) {
     constexpr int G = N + 1;
     const QdLayout L = qd_layout(N);
     const int slot = blockIdx.z;
@@ -142,6 +192,18 @@ qd_k_ground(const int* __restrict__ env_ids, int env_base, int R, const double* 
     __syncthreads();
     const int half = threadIdx.x >> 5;                       // 0..7
     QdWaveLds& W = sW[threadIdx.x >> 6];
+    const double* st = state + (size_t)e * L.s_size;
+    const uint32_t k1 = nz.env_off + (uint32_t)e;
+    if (qd_radial_replaced(par, st, L, ch, nz.flags)) {
+        // qarray_base_class.py:466-468: np.random.randn(*z.shape)
+        const int p = blockIdx.x * QD_GS_PPB + threadIdx.x;
+        if (threadIdx.x < QD_GS_PPB && p < P) {
+            const QdPhilox r = qd_philox4x32_10((uint32_t)p, (uint32_t)ch | (QD_RNG_RADIAL << 16), nz.ser_lo, nz.ser_hi, nz.seed, k1);
+            double z0, z1; qd_normal2(r, z0, z1);
+            zraw[((size_t)e * (N - 1) + ch) * P + p] = z0;
+        }
+        return;
+    }
     const QdPixelRec* rbase = recs + ((size_t)slot * (N - 1) + ch) * P;
     const int p0 = blockIdx.x * QD_GS_PPB;
     for (int it = 0; it < QD_GS_PPB / 8; ++it) {
@@ -157,6 +219,15 @@ qd_k_ground(const int* __restrict__ env_ids, int env_base, int R, const double* 
             const double* pvv = W.pv[(threadIdx.x >> 5) & 1];
             const double vs = pvv[N];
             const double Ns = rint(vs);
+            // sensor-potential noise: white (Gaussian) + telegraph (TunnelCoupledChargeSensed.py:354)
+            double eta = 0.0;
+            if (nz.flags & 1) {
+                const QdPhilox r = qd_philox4x32_10((uint32_t)p, (uint32_t)ch | (QD_RNG_WHITE << 16), nz.ser_lo, nz.ser_hi, nz.seed, k1);
+                double z0, z1; qd_normal2(r, z0, z1);
+                eta = par[L.noise + 0] * z0;
+                const unsigned long long w = nz.tel[((size_t)e * (N - 1) + ch) * nz.tel_words + (p >> 6)];
+                if ((w >> (p & 63)) & 1ull) eta += par[L.noise + 3];
+            }
             double b = 0.0;
 #pragma unroll
             for (int i = 0; i < N; ++i) b = fma(sA[N * G + i], occ[i] - pvv[i], b);
@@ -165,10 +236,24 @@ qd_k_ground(const int* __restrict__ env_ids, int env_base, int R, const double* 
             double s = 0.0;
 #pragma unroll
             for (int k = -QD_NPEAK; k < QD_NPEAK; ++k) {
-                const double xk = (Ns + (double)k) - vs;
+                const double xk = ((Ns + (double)k) + eta) - vs;
                 const double dF = 2.0 * b + a * (2.0 * xk + 1.0);
                 const double rr = dF / gamma;
                 s += 1.0 / (rr * rr + 1.0);
+            }
+            if (nz.flags & 2) {
+                // qarray_base_class.py:470-493: z + randn * clip(alpha (dist - zero_radius), 0, max_amplitude)
+                const double w_ = par[L.scal + 2];
+                const int y_ = p / R, x_ = p - y_ * R;
+                const double v1 = st[L.s_gate_v + ch], v2 = st[L.s_gate_v + ch + 1];
+                const double V1 = qd_linspace(v1 + (-w_), v1 + w_, R, x_), V2 = qd_linspace(v2 + (-w_), v2 + w_, R, y_);
+                const double g1 = V1 - st[L.s_gate_gt + ch], g2 = V2 - st[L.s_gate_gt + ch + 1];
+                const double dist = sqrt(g1 * g1 + g2 * g2);
+                const double alpha = par[L.noise + 7] / par[L.noise + 5];
+                const double amp = fmin(fmax(alpha * (dist - par[L.noise + 4]), 0.0), par[L.noise + 7]);
+                const QdPhilox r = qd_philox4x32_10((uint32_t)p, (uint32_t)ch | (QD_RNG_RADIAL << 16), nz.ser_lo, nz.ser_hi, nz.seed, k1);
+                double z0, z1; qd_normal2(r, z0, z1);
+                s += z0 * amp;
             }
             zraw[((size_t)e * (N - 1) + ch) * P + p] = s;
             if (occ_out) {

@@ -11,6 +11,8 @@ CSRC = os.path.join(os.path.dirname(_HERE), "csrc")
 LIB_PATH = os.path.join(CSRC, "libqdsim.so")
 
 QD_FLAG_VALIDATE = 1
+QD_NOISE_SENSOR = 1
+QD_NOISE_RADIAL = 2
 
 EXPORTS = [
     "qd_param_block_doubles", "qd_state_block_doubles", "qd_layout_query", "qd_create", "qd_destroy",
@@ -24,11 +26,12 @@ class QdConfig(ctypes.Structure):
     _fields_ = [
         ("struct_size", ctypes.c_int32), ("n_dot", ctypes.c_int32), ("resolution", ctypes.c_int32),
         ("batch", ctypes.c_int32), ("max_steps", ctypes.c_int32), ("env_chunk", ctypes.c_int32),
-        ("flags", ctypes.c_int32), ("reserved", ctypes.c_int32),
+        ("flags", ctypes.c_int32), ("noise_flags", ctypes.c_int32),
         ("gate_ramp_start", ctypes.c_double), ("gate_quadratic_start", ctypes.c_double),
         ("barrier_ramp_start", ctypes.c_double), ("kalman_prior_mean", ctypes.c_double),
         ("kalman_prior_variance", ctypes.c_double), ("kalman_prior_mean_nnn", ctypes.c_double),
         ("kalman_variance_threshold", ctypes.c_double), ("kalman_process_noise", ctypes.c_double),
+        ("rng_seed", ctypes.c_uint64), ("env_id_offset", ctypes.c_int64),
     ]
 
 

@@ -271,6 +271,27 @@ class DeviceSampler:
         P[:, L.bmin:L.bmin + nb] = bmin; P[:, L.bmax:L.bmax + nb] = bmax
         P[:, L.scal + 0] = a["tc_base"]; P[:, L.scal + 1] = a["coulomb_peak_width"]
         P[:, L.scal + 2] = a["window_delta"]
+        # a16 noise parameters (drawn in the reference order above; used only when the handle
+        # is created with the corresponding noise flags)
+        P[:, L.noise + 0] = a["white_noise_amplitude"]
+        P[:, L.noise + 1] = a["telegraph"]["p01"]; P[:, L.noise + 2] = a["telegraph"]["p10"]
+        P[:, L.noise + 3] = a["telegraph"]["amplitude"]
+        rn = self.ecfg["simulator"].get("radial_noise") or {"enabled": False}
+        if rn.get("enabled"):
+            col = 0
+            def take(v):
+                nonlocal col
+                if isinstance(v, dict):
+                    out = a["radial"][:, col]; col += 1
+                    return out
+                return np.full(n, float(v))
+            zr = take(rn["lower"]); dl = take(rn["ramp_range"])
+            tn = rn.get("total_noise_range")
+            full = take(tn) if isinstance(tn, dict) else np.full(n, -1.0)
+            P[:, L.noise + 4] = zr; P[:, L.noise + 5] = zr + dl; P[:, L.noise + 6] = full
+            P[:, L.noise + 7] = float(rn["max_amplitude"])
+        else:
+            P[:, L.noise + 6] = -1.0
         S = eb.state
         S[:, L.s_vgm:L.s_vgm + G * G] = vgm0.reshape(-1)
         S[:, L.s_gate_v:L.s_gate_v + N] = pmin + (pmax - pmin) * a["u_start_plunger"]

@@ -24,6 +24,7 @@ class Layout:
     bmin: int
     bmax: int
     scal: int
+    noise: int
     size: int
     s_vgm: int
     s_gate_v: int
@@ -42,7 +43,7 @@ def layout(N: int) -> Layout:
     f = {}
     for name, n in (("cdd_inv", G * G), ("cgd", G * V), ("cbg", nb * G), ("ufac", N * N), ("uinv", N),
                     ("alpha", nb), ("origin", G), ("vopt", G), ("vbopt", nb), ("pmin", N),
-                    ("pmax", N), ("bmin", nb), ("bmax", nb), ("scal", 4)):
+                    ("pmax", N), ("bmin", nb), ("bmax", nb), ("scal", 4), ("noise", 8)):
         f[name] = o
         o += n
     f["size"] = (o + 1) & ~1
@@ -56,6 +57,6 @@ def layout(N: int) -> Layout:
 
 
 LAYOUT_FIELDS = ["N", "G", "nb", "V", "cdd_inv", "cgd", "cbg", "ufac", "uinv", "alpha", "origin", "vopt",
-                 "vbopt", "pmin", "pmax", "bmin", "bmax", "scal", "size", "s_vgm", "s_gate_v",
+                 "vbopt", "pmin", "pmax", "bmin", "bmax", "scal", "noise", "size", "s_vgm", "s_gate_v",
                  "s_barrier_v", "s_gate_gt", "s_barrier_gt", "s_sensor_gt", "s_kmean", "s_kvar",
                  "s_size"]

@@ -53,7 +53,7 @@ class SyntheticCapacitanceModel:
 class VecQuantumDeviceEnv:
     def __init__(self, num_envs, num_dots=None, config_path=None, qarray_config_path=None,
                  resolution=None, device=None, seed=1234, env_id_offset=0, capacitance_model=None,
-                 validate=False, env_chunk=0, reset_kalman_on_reset=False):
+                 validate=False, env_chunk=0, reset_kalman_on_reset=False, noise=None):
         self.config = load_yaml(config_path, "env_config.yaml")
         self.qconfig = load_yaml(qarray_config_path, "qarray_config.yaml")
         sim = self.config["simulator"]
@@ -92,13 +92,14 @@ class VecQuantumDeviceEnv:
         rew = self.config["reward"]; cm = self.config["capacitance_model"]
         cfg = _lib.QdConfig(struct_size=ctypes.sizeof(_lib.QdConfig), n_dot=N, resolution=R, batch=B,
                             max_steps=self.max_steps, env_chunk=int(env_chunk),
-                            flags=_lib.QD_FLAG_VALIDATE if validate else 0, reserved=0,
+                            flags=_lib.QD_FLAG_VALIDATE if validate else 0, noise_flags=self._noise_flags(noise),
                             gate_ramp_start=float(rew["gate_ramp_start"]),
                             gate_quadratic_start=float(rew["gate_quadratic_start"]),
                             barrier_ramp_start=float(rew["barrier_ramp_start"]),
                             kalman_prior_mean=0.3, kalman_prior_variance=0.5, kalman_prior_mean_nnn=0.15,
                             kalman_variance_threshold=float(cm.get("variance_threshold", 0.05)),
-                            kalman_process_noise=float(cm.get("process_noise", 0.0)))
+                            kalman_process_noise=float(cm.get("process_noise", 0.0)),
+                            rng_seed=int(seed) & 0xFFFFFFFFFFFFFFFF, env_id_offset=int(env_id_offset))
         self._h = ctypes.c_void_p()
         rc = self._lib.qd_create(ctypes.byref(cfg), self.device.index or 0, ctypes.byref(self._h))
         _lib.check(self._h, rc, "qd_create")
@@ -119,6 +120,20 @@ class VecQuantumDeviceEnv:
         self._needs_reset = True
 
     # ------------------------------------------------------------------ helpers
+    def _noise_flags(self, noise):
+        """noise=None/False: deterministic parity mode.  noise=True: what the configs enable
+        (sensor white + telegraph noise always, radial noise if simulator.radial_noise.enabled).
+        Or an iterable of {"sensor", "radial"}."""
+        if not noise:
+            return 0
+        if noise is True:
+            rn = self.config["simulator"].get("radial_noise") or {}
+            return _lib.QD_NOISE_SENSOR | (_lib.QD_NOISE_RADIAL if rn.get("enabled") else 0)
+        f = 0
+        for k in noise:
+            f |= {"sensor": _lib.QD_NOISE_SENSOR, "radial": _lib.QD_NOISE_RADIAL}[k]
+        return f
+
     def _stream(self):
         return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 

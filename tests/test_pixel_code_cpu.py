@@ -48,3 +48,24 @@ def test_search_prunes(capsys):
     nodes, leaves, inserts, shifts = (got["stats"] / (R * R)).tolist()
     print(f"N=8 search per pixel: nodes {nodes:.0f} leaves {leaves:.0f} inserts {inserts:.0f}")
     assert leaves < 4 ** 8 / 20
+
+
+def test_philox_known_answers_and_normals():
+    """Philox4x32-10 known-answer vectors (Random123 kat_vectors) and the Box-Muller transform
+    used by the stochastic stages (csrc/qd_rng.h), on the CPU build of the device code."""
+    import ctypes
+    h = H.hosttest()
+    out = (ctypes.c_uint32 * 4)()
+    h.qdh_philox(0, 0, 0, 0, 0, 0, out)
+    assert [hex(v) for v in out] == ['0x6627e8d5', '0xe169c58d', '0xbc57ac4c', '0x9b00dbd8']
+    f = 0xFFFFFFFF
+    h.qdh_philox(f, f, f, f, f, f, out)
+    assert [hex(v) for v in out] == ['0x408f276d', '0x41c83b0e', '0xa20bc7c6', '0x6d5451fd']
+    h.qdh_philox(0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344, 0xa4093822, 0x299f31d0, out)
+    assert [hex(v) for v in out] == ['0xd16cfe09', '0x94fdcceb', '0x5001e420', '0x24126ea1']
+    n = 200000
+    z = np.zeros(n)
+    h.qdh_normals(123, 456, n, z.ctypes.data_as(ctypes.POINTER(ctypes.c_double)))
+    assert abs(z.mean()) < 0.01 and abs(z.std() - 1) < 0.01
+    assert abs(np.mean(z ** 3)) < 0.03 and abs(np.mean(z ** 4) - 3) < 0.08
+    assert abs(np.corrcoef(z[0::2], z[1::2])[0, 1]) < 0.01
