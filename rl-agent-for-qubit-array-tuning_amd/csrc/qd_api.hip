@@ -217,7 +217,7 @@ static QdNoiseCfg qd_noise_cfg(const qd_handle* h) {
 static int qd_launch_ground(qd_handle* h, const int32_t* env_ids, int base, int cnt, hipStream_t s) {
     dim3 g2((h->P + QD_GS_PPB - 1) / QD_GS_PPB, h->C, cnt);
     QD_DISPATCH_N(h->N, qd_k_ground<NN><<<g2, dim3(QD_GS_BLOCK), 0, s>>>(env_ids, base, h->R,
-                                            h->params, h->recs, h->zraw, h->occ, h->state, qd_noise_cfg(h)));
+                                            h->params, h->recs, h->zraw, h->occ, h->state, h->cfg.noise_flags));
     QD_HIP(hipGetLastError());
     return QD_OK;
 }
@@ -244,6 +244,11 @@ extern "C" int qd_observe(qd_handle* h, const int32_t* env_ids, int n, void* str
         QD_HIP(hipGetLastError());
         int rc = qd_launch_ground(h, env_ids, base, cnt, s);
         if (rc) return rc;
+    }
+    {
+        dim3 g3((h->P + 255) / 256, h->C, n);
+        QD_DISPATCH_N(h->N, qd_k_sensor<NN><<<g3, dim3(256), 0, s>>>(env_ids, h->R, h->params, h->state, h->zraw, qd_noise_cfg(h)));
+        QD_HIP(hipGetLastError());
     }
     qd_k_percentile<<<dim3(n), dim3(QD_PCT_BLOCK), 0, s>>>(env_ids, (long)h->C * h->P, h->zraw, h->plohi);
     QD_HIP(hipGetLastError());

@@ -215,6 +215,9 @@ __device__ void qd_ground_pixel(const double* __restrict__ A, const QdPixelRec* 
         const bool hop = ay != 0 && (ay >> tz) == 15u && (tz & 3) == 0 && ((tcnz >> (N - 2 - (tz >> 2))) & 1u);
         if (hop && valid && j < nvalid) nbrmask |= 1u << j;
     }
+#if defined(QD_ABLATE) && QD_ABLATE == 4
+    nbrmask = 0;                                          // diagnostic: no hopping at all
+#endif
     const int cnt = __popc(nbrmask);
     const int maxcnt = qd_wave_max_int(cnt);
     {
@@ -280,7 +283,11 @@ __device__ void qd_ground_pixel(const double* __restrict__ A, const QdPixelRec* 
     const bool active = comp_lower <= upper_all;
 
     // ---- 5. Lanczos pass 1: T ----------------------------------------------
+#if defined(QD_ABLATE) && QD_ABLATE == 3
+    const bool solve = false;                              // diagnostic: skip Lanczos/Laguerre/inverse iteration
+#else
     const bool solve = active && ssz > 1;
+#endif
     const double q0 = solve ? 1.0 / sqrt((double)ssz) : 0.0;
     double q = q0, qp = 0.0, bp = 0.0, anorm = 0.0;
     double al_mine = F, be_mine = 0.0, ib_mine = 0.0;      // singleton: T = [F]
@@ -338,33 +345,55 @@ __device__ void qd_ground_pixel(const double* __restrict__ A, const QdPixelRec* 
     const double tscale = fmax(fmax(fabs(lo), fabs(hi)), qd_seg_max((r < k - 1) ? fabs(be_mine) : 0.0, seg, smax, buf, hb));
     double xl = lo - (1e-3 * tscale + 1e-300);
     {
+#if defined(QD_ABLATE) && QD_ABLATE == 1
+        bool conv = true;                                  // diagnostic: skip Laguerre
+#else
         bool conv = k <= 1;
+#endif
         const double dk = (double)k;
         for (int it = 0; it < 48; ++it) {
             if (!__any(!conv)) break;
-            // p, p', p'' at xl
-            double p0 = 1.0, p1 = 0.0, d0 = 0.0, d1 = 0.0, e0 = 0.0, e1 = 0.0, bprev = 0.0;
-            unsigned mm = seg;
-            for (int i = 0; i < kmax; ++i) {
-                if (i < k) {
-                    const int b = __builtin_ctz(mm); mm &= mm - 1;
-                    const double a = al[hb + b] - xl;
-                    const double b2 = bprev * bprev;
-                    double p2, d2, e2;
-                    if (i == 0) { p2 = a; d2 = -1.0; e2 = 0.0; p1 = 1.0; }
-                    else {
-                        p2 = fma(a, p1, -(b2 * p0));
-                        d2 = fma(a, d1, -(b2 * d0)) - p1;
-                        e2 = fma(a, e1, -(b2 * e0)) - 2.0 * d1;
+            // p, p', p'' at xl: three-term recurrences over the rows of T.  The first 8 rows use the
+            // register-resident member slots (no bit scanning); magnitudes are rescaled every 4 rows.
+            double p0 = 1.0, p1 = 1.0, d0 = 0.0, d1 = 0.0, e0 = 0.0, e1 = 0.0, bprev = 0.0;
+#define QD_LAG_ROW(AL, BE, FIRST)                                                   \
+            {                                                                       \
+                const double a_ = (AL) - xl;                                        \
+                const double b2_ = bprev * bprev;                                   \
+                double p2_, d2_, e2_;                                               \
+                if (FIRST) { p2_ = a_; d2_ = -1.0; e2_ = 0.0; }                     \
+                else {                                                              \
+                    p2_ = fma(a_, p1, -(b2_ * p0));                                 \
+                    d2_ = fma(a_, d1, -(b2_ * d0)) - p1;                            \
+                    e2_ = fma(a_, e1, -(b2_ * e0)) - 2.0 * d1;                      \
+                }                                                                   \
+                p0 = p1; p1 = p2_; d0 = d1; d1 = d2_; e0 = e1; e1 = e2_;            \
+                bprev = (BE);                                                       \
+            }
+#define QD_LAG_RESCALE()                                                            \
+            {                                                                       \
+                const double ap_ = fabs(p1);                                        \
+                double sc_ = 1.0;                                                   \
+                if (ap_ > 1e100) sc_ = 1e-100; else if (ap_ < 1e-100 && ap_ > 0.0) sc_ = 1e100; \
+                if (sc_ != 1.0) { p0 *= sc_; p1 *= sc_; d0 *= sc_; d1 *= sc_; e0 *= sc_; e1 *= sc_; } \
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (i < k) { QD_LAG_ROW(al[MB.idx[i]], be[MB.idx[i]], i == 0) }
+                if ((i & 3) == 3) QD_LAG_RESCALE()
+            }
+            {
+                unsigned mm = MB.rest;
+                for (int i = 8; i < kmax; ++i) {
+                    if (i < k) {
+                        const int b = __builtin_ctz(mm); mm &= mm - 1;
+                        QD_LAG_ROW(al[hb + b], be[hb + b], false)
                     }
-                    p0 = p1; p1 = p2; d0 = d1; d1 = d2; e0 = e1; e1 = e2;
-                    const double ap = fabs(p1);
-                    double sc = 1.0;
-                    if (ap > 1e100) sc = 1e-100; else if (ap < 1e-100 && ap > 0.0) sc = 1e100;
-                    if (sc != 1.0) { p0 *= sc; p1 *= sc; d0 *= sc; d1 *= sc; e0 *= sc; e1 *= sc; }
-                    bprev = be[hb + b];
+                    if ((i & 3) == 3) QD_LAG_RESCALE()
                 }
             }
+#undef QD_LAG_ROW
+#undef QD_LAG_RESCALE
             if (!conv) {
                 if (p1 == 0.0) conv = true;
                 else {
@@ -458,7 +487,11 @@ __device__ void qd_ground_pixel(const double* __restrict__ A, const QdPixelRec* 
     double x = solve ? 0.0 : 1.0;
     {
         double q2 = q0, qp2 = 0.0, bp2 = 0.0;
+#if defined(QD_ABLATE) && QD_ABLATE == 2
+        bool done2 = true;                                 // diagnostic: skip pass 2
+#else
         bool done2 = !solve;
+#endif
         unsigned mm = seg;
         for (int j = 0; j < jmax; ++j) {
             if (!__any(!done2)) break;

@@ -176,7 +176,7 @@ template <int N>
 __global__ void __launch_bounds__(QD_GS_BLOCK)
 qd_k_ground(const int* __restrict__ env_ids, int env_base, int R, const double* __restrict__ params,
             const QdPixelRec* __restrict__ recs, double* __restrict__ zraw, double* __restrict__ occ_out,
-            const double* __restrict__ state, QdNoiseCfg nz) {
+            const double* __restrict__ state, int noise_flags) {
     constexpr int G = N + 1;
     const QdLayout L = qd_layout(N);
     const int slot = blockIdx.z;
@@ -187,23 +187,12 @@ qd_k_ground(const int* __restrict__ env_ids, int env_base, int R, const double* 
     __shared__ QdWaveLds sW[QD_GS_BLOCK / 64];
     const double* par = params + (size_t)e * L.size;
     for (int i = threadIdx.x; i < G * G; i += QD_GS_BLOCK) sA[i] = par[L.cdd_inv + i];
-    if (threadIdx.x == 0) sA[G * G] = par[L.scal + 1];       // gamma
     if (threadIdx.x < QD_GS_BLOCK / 64) { sW[threadIdx.x].buf[64] = 0.0; sW[threadIdx.x].buf[65] = 0.0; }
     __syncthreads();
     const int half = threadIdx.x >> 5;                       // 0..7
     QdWaveLds& W = sW[threadIdx.x >> 6];
     const double* st = state + (size_t)e * L.s_size;
-    const uint32_t k1 = nz.env_off + (uint32_t)e;
-    if (qd_radial_replaced(par, st, L, ch, nz.flags)) {
-        // qarray_base_class.py:466-468: np.random.randn(*z.shape)
-        const int p = blockIdx.x * QD_GS_PPB + threadIdx.x;
-        if (threadIdx.x < QD_GS_PPB && p < P) {
-            const QdPhilox r = qd_philox4x32_10((uint32_t)p, (uint32_t)ch | (QD_RNG_RADIAL << 16), nz.ser_lo, nz.ser_hi, nz.seed, k1);
-            double z0, z1; qd_normal2(r, z0, z1);
-            zraw[((size_t)e * (N - 1) + ch) * P + p] = z0;
-        }
-        return;
-    }
+    if (qd_radial_replaced(par, st, L, ch, noise_flags)) return;   // qd_k_sensor writes pure noise
     const QdPixelRec* rbase = recs + ((size_t)slot * (N - 1) + ch) * P;
     const int p0 = blockIdx.x * QD_GS_PPB;
     for (int it = 0; it < QD_GS_PPB / 8; ++it) {
@@ -215,53 +204,85 @@ qd_k_ground(const int* __restrict__ env_ids, int env_base, int R, const double* 
         double occ[N], lam;
         qd_ground_pixel<N>(sA, rec, W, occ, &lam);
         if ((threadIdx.x & 31) == 0 && p < P) {
-            // sensor stage (closed-form differences, qd_pixel.h); vpp staged in LDS by qd_ground_pixel
+            // hand the sensor stage (qd_k_sensor) the pixel's constant c0 = 2 b + a (2 (Ns - v''_s) + 1):
+            // F_{k+1} - F_k = c0 + 2 a (k + eta)   (closed form of the reference's energy differences)
             const double* pvv = W.pv[(threadIdx.x >> 5) & 1];
             const double vs = pvv[N];
-            const double Ns = rint(vs);
-            // sensor-potential noise: white (Gaussian) + telegraph (TunnelCoupledChargeSensed.py:354)
-            double eta = 0.0;
-            if (nz.flags & 1) {
-                const QdPhilox r = qd_philox4x32_10((uint32_t)p, (uint32_t)ch | (QD_RNG_WHITE << 16), nz.ser_lo, nz.ser_hi, nz.seed, k1);
-                double z0, z1; qd_normal2(r, z0, z1);
-                eta = par[L.noise + 0] * z0;
-                const unsigned long long w = nz.tel[((size_t)e * (N - 1) + ch) * nz.tel_words + (p >> 6)];
-                if ((w >> (p & 63)) & 1ull) eta += par[L.noise + 3];
-            }
+            const double Ns = rint(vs);                                 // np.round: half to even
             double b = 0.0;
 #pragma unroll
             for (int i = 0; i < N; ++i) b = fma(sA[N * G + i], occ[i] - pvv[i], b);
             const double a = sA[N * G + N];
-            const double gamma = sA[G * G];
-            double s = 0.0;
-#pragma unroll
-            for (int k = -QD_NPEAK; k < QD_NPEAK; ++k) {
-                const double xk = ((Ns + (double)k) + eta) - vs;
-                const double dF = 2.0 * b + a * (2.0 * xk + 1.0);
-                const double rr = dF / gamma;
-                s += 1.0 / (rr * rr + 1.0);
-            }
-            if (nz.flags & 2) {
-                // qarray_base_class.py:470-493: z + randn * clip(alpha (dist - zero_radius), 0, max_amplitude)
-                const double w_ = par[L.scal + 2];
-                const int y_ = p / R, x_ = p - y_ * R;
-                const double v1 = st[L.s_gate_v + ch], v2 = st[L.s_gate_v + ch + 1];
-                const double V1 = qd_linspace(v1 + (-w_), v1 + w_, R, x_), V2 = qd_linspace(v2 + (-w_), v2 + w_, R, y_);
-                const double g1 = V1 - st[L.s_gate_gt + ch], g2 = V2 - st[L.s_gate_gt + ch + 1];
-                const double dist = sqrt(g1 * g1 + g2 * g2);
-                const double alpha = par[L.noise + 7] / par[L.noise + 5];
-                const double amp = fmin(fmax(alpha * (dist - par[L.noise + 4]), 0.0), par[L.noise + 7]);
-                const QdPhilox r = qd_philox4x32_10((uint32_t)p, (uint32_t)ch | (QD_RNG_RADIAL << 16), nz.ser_lo, nz.ser_hi, nz.seed, k1);
-                double z0, z1; qd_normal2(r, z0, z1);
-                s += z0 * amp;
-            }
-            zraw[((size_t)e * (N - 1) + ch) * P + p] = s;
+            zraw[((size_t)e * (N - 1) + ch) * P + p] = 2.0 * b + a * (2.0 * (Ns - vs) + 1.0);
             if (occ_out) {
 #pragma unroll
                 for (int i = 0; i < N; ++i) occ_out[(((size_t)e * (N - 1) + ch) * P + p) * N + i] = occ[i];
             }
         }
     }
+}
+
+// ---------------------------------------------------------------------------
+// a15 + a16: sensor stage, one pixel per lane, in place on zraw.
+//   in : c0 from qd_k_ground      out: signal = sum_{k=-5..4} 1 / (((c0 + 2 a (k + eta)) / gamma)^2 + 1)
+// eta = sensor-potential noise (white + telegraph), then radial image noise / replacement.
+// grid = (ceil(P/256), C, n_env)
+// ---------------------------------------------------------------------------
+template <int N>
+__global__ void qd_k_sensor(const int* __restrict__ env_ids, int R, const double* __restrict__ params,
+                            const double* __restrict__ state, double* __restrict__ zraw, QdNoiseCfg nz) {
+    constexpr int G = N + 1;
+    const QdLayout L = qd_layout(N);
+    const int e = env_ids ? env_ids[blockIdx.z] : blockIdx.z;
+    const int ch = blockIdx.y;
+    const int P = R * R;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    const double* par = params + (size_t)e * L.size;
+    const double* st = state + (size_t)e * L.s_size;
+    const uint32_t k1 = nz.env_off + (uint32_t)e;
+    double* zp = zraw + ((size_t)e * (N - 1) + ch) * P + p;
+    if (qd_radial_replaced(par, st, L, ch, nz.flags)) {
+        // qarray_base_class.py:466-468: np.random.randn(*z.shape)
+        const QdPhilox r = qd_philox4x32_10((uint32_t)p, (uint32_t)ch | (QD_RNG_RADIAL << 16), nz.ser_lo, nz.ser_hi, nz.seed, k1);
+        double z0, z1; qd_normal2(r, z0, z1);
+        *zp = z0;
+        return;
+    }
+    const double c0 = *zp;
+    const double a = par[L.cdd_inv + N * G + N];
+    const double gamma = par[L.scal + 1];
+    double eta = 0.0;
+    if (nz.flags & 1) {
+        // TunnelCoupledChargeSensed.py:354: input noise on the sensor potential (white + telegraph)
+        const QdPhilox r = qd_philox4x32_10((uint32_t)p, (uint32_t)ch | (QD_RNG_WHITE << 16), nz.ser_lo, nz.ser_hi, nz.seed, k1);
+        double z0, z1; qd_normal2(r, z0, z1);
+        eta = par[L.noise + 0] * z0;
+        const unsigned long long w = nz.tel[((size_t)e * (N - 1) + ch) * nz.tel_words + (p >> 6)];
+        if ((w >> (p & 63)) & 1ull) eta += par[L.noise + 3];
+    }
+    double s = 0.0;
+#pragma unroll
+    for (int k = -QD_NPEAK; k < QD_NPEAK; ++k) {
+        const double dF = c0 + 2.0 * a * ((double)k + eta);
+        const double rr = dF / gamma;
+        s += 1.0 / (rr * rr + 1.0);
+    }
+    if (nz.flags & 2) {
+        // qarray_base_class.py:470-493: z + randn * clip(alpha (dist - zero_radius), 0, max_amplitude)
+        const double w_ = par[L.scal + 2];
+        const int y_ = p / R, x_ = p - y_ * R;
+        const double v1 = st[L.s_gate_v + ch], v2 = st[L.s_gate_v + ch + 1];
+        const double V1 = qd_linspace(v1 + (-w_), v1 + w_, R, x_), V2 = qd_linspace(v2 + (-w_), v2 + w_, R, y_);
+        const double g1 = V1 - st[L.s_gate_gt + ch], g2 = V2 - st[L.s_gate_gt + ch + 1];
+        const double dist = sqrt(g1 * g1 + g2 * g2);
+        const double alpha = par[L.noise + 7] / par[L.noise + 5];
+        const double amp = fmin(fmax(alpha * (dist - par[L.noise + 4]), 0.0), par[L.noise + 7]);
+        const QdPhilox r = qd_philox4x32_10((uint32_t)p, (uint32_t)ch | (QD_RNG_RADIAL << 16), nz.ser_lo, nz.ser_hi, nz.seed, k1);
+        double z0, z1; qd_normal2(r, z0, z1);
+        s += z0 * amp;
+    }
+    *zp = s;
 }
 
 // ---------------------------------------------------------------------------

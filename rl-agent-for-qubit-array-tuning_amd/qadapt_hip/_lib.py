@@ -8,7 +8,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(os.path.dirname(_HERE), "csrc")
-LIB_PATH = os.path.join(CSRC, "libqdsim.so")
+LIB_PATH = os.environ.get("QDSIM_LIB", os.path.join(CSRC, "libqdsim.so"))   # QDSIM_LIB: diagnostic builds
 
 QD_FLAG_VALIDATE = 1
 QD_NOISE_SENSOR = 1
