@@ -35,6 +35,9 @@
 #if defined(__HIPCC__)
 
 #define QD_NBMAX 14                 // a state has at most 2*(N-1) hop neighbours
+#ifndef QD_NBREG
+#define QD_NBREG 3                  // neighbour slots kept in registers for the matvecs
+#endif
 
 struct QdWaveLds {
     double coef[QD_NBMAX][64];      // H_ij of neighbour slot s of lane
@@ -108,19 +111,21 @@ __device__ __forceinline__ double qd_seg_sum(double v, const QdMembers& M, volat
     __builtin_amdgcn_wave_barrier();
     return acc;
 }
-__device__ __forceinline__ double qd_seg_min(double v, unsigned seg, int smax, volatile double* buf, int hb) {
+__device__ __forceinline__ double qd_seg_min(double v, const QdMembers& M, int ssz, volatile double* buf, int hb) {
     buf[threadIdx.x & 63] = v;
     __builtin_amdgcn_wave_barrier();
     double acc = INFINITY;
-    unsigned mm = seg;
-    for (int it = 0; it < smax; ++it) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { const double t = buf[M.idx[i]]; acc = (i < ssz) ? fmin(acc, t) : acc; }
+    unsigned mm = M.rest;
+    for (int it = 0; it < M.nrest_max; ++it) {
         if (mm) { int b = __builtin_ctz(mm); mm &= mm - 1; acc = fmin(acc, buf[hb + b]); }
     }
     __builtin_amdgcn_wave_barrier();
     return acc;
 }
-__device__ __forceinline__ double qd_seg_max(double v, unsigned seg, int smax, volatile double* buf, int hb) {
-    return -qd_seg_min(-v, seg, smax, buf, hb);
+__device__ __forceinline__ double qd_seg_max(double v, const QdMembers& M, int ssz, volatile double* buf, int hb) {
+    return -qd_seg_min(-v, M, ssz, buf, hb);
 }
 
 // Sturm count (number of eigenvalues < lam) of the k x k tridiagonal whose rows
@@ -247,12 +252,23 @@ __device__ void qd_ground_pixel(const double* __restrict__ A, const QdPixelRec* 
         }
     }
 
+    // the first 6 neighbour slots stay in registers for the matvecs (typical degree <= 6)
+    double nbc[QD_NBREG + 1]; int nbi[QD_NBREG + 1];
+#pragma unroll
+    for (int i = 0; i < QD_NBREG; ++i) {
+        nbc[i] = (i < maxcnt) ? W.coef[i][lane] : 0.0;
+        nbi[i] = (i < maxcnt) ? (int)W.nidx[i][lane] : m;
+    }
+
     // ---- 3. connected components (reach masks) -----------------------------
     unsigned seg = 1u << m;
     if (valid) seg |= nbrmask;
     for (int guard = 0; guard < 32; ++guard) {
         unsigned nw = seg;
-        for (int s = 0; s < maxcnt; ++s) {
+#pragma unroll
+        for (int i = 0; i < QD_NBREG; ++i)
+            if (i < maxcnt) { const unsigned r2 = __shfl(seg, nbi[i], 32); if (i < cnt) nw |= r2; }
+        for (int s = QD_NBREG; s < maxcnt; ++s) {
             const unsigned r2 = __shfl(seg, (int)W.nidx[s][lane], 32);
             if (s < cnt) nw |= r2;
         }
@@ -279,7 +295,7 @@ __device__ void qd_ground_pixel(const double* __restrict__ A, const QdPixelRec* 
     double radius = 0.0;
     for (int s = 0; s < maxcnt; ++s) radius += fabs(W.coef[s][lane]);
     const double upper_all = qd_half_min(F);
-    const double comp_lower = qd_seg_min(F - radius, seg, smax, buf, hb);
+    const double comp_lower = qd_seg_min(F - radius, MB, ssz, buf, hb);
     const bool active = comp_lower <= upper_all;
 
     // ---- 5. Lanczos pass 1: T ----------------------------------------------
@@ -297,7 +313,10 @@ __device__ void qd_ground_pixel(const double* __restrict__ A, const QdPixelRec* 
     for (int j = 0; j < jmax; ++j) {
         if (!__any(!done)) break;
         double w = F * q;
-        for (int s = 0; s < maxcnt; ++s) {
+#pragma unroll
+        for (int i = 0; i < QD_NBREG; ++i)
+            if (i < maxcnt) { const double qj = __shfl(q, nbi[i], 32); w = fma(nbc[i], qj, w); }
+        for (int s = QD_NBREG; s < maxcnt; ++s) {
             const double qj = __shfl(q, (int)W.nidx[s][lane], 32);
             w = fma(W.coef[s][lane], qj, w);
         }
@@ -339,10 +358,10 @@ __device__ void qd_ground_pixel(const double* __restrict__ A, const QdPixelRec* 
         const double bprev = (r > 0 && r < k) ? be[hb + prev] : 0.0;
         const double bme = (r < k - 1) ? be_mine : 0.0;
         const double g = (r < k) ? al_mine - fabs(bprev) - fabs(bme) : INFINITY;
-        lo = qd_seg_min(g, seg, smax, buf, hb);                       // Gershgorin lower bound
-        hi = qd_seg_min((r < k) ? al_mine : INFINITY, seg, smax, buf, hb);
+        lo = qd_seg_min(g, MB, ssz, buf, hb);                       // Gershgorin lower bound
+        hi = qd_seg_min((r < k) ? al_mine : INFINITY, MB, ssz, buf, hb);
     }
-    const double tscale = fmax(fmax(fabs(lo), fabs(hi)), qd_seg_max((r < k - 1) ? fabs(be_mine) : 0.0, seg, smax, buf, hb));
+    const double tscale = fmax(fmax(fabs(lo), fabs(hi)), qd_seg_max((r < k - 1) ? fabs(be_mine) : 0.0, MB, ssz, buf, hb));
     double xl = lo - (1e-3 * tscale + 1e-300);
     {
 #if defined(QD_ABLATE) && QD_ABLATE == 1
@@ -421,61 +440,72 @@ __device__ void qd_ground_pixel(const double* __restrict__ A, const QdPixelRec* 
     // ---- 6b. eigenvector of T: inverse iteration, SPD factorisation at sigma = lo
     // (T - lo) = L D L^T.  Every member lane runs the same serial recurrences and
     // writes identical values: rd[row i] = 1/d_i, lf[row i] = l_{i-1}, yv[row i] = y_i.
+    // Rows 0..7 are addressed through the register-resident member slots.
     {
         const double sig = lo;
         const double tiny = 1e-300 + 1e-18 * fmax(fabs(lo), fabs(hi));
-        unsigned mm = seg;
         double d = 1.0, bprev = 0.0;
-        for (int i = 0; i < kmax; ++i) {
-            if (i < k) {
-                const int b = __builtin_ctz(mm); mm &= mm - 1;
-                const double a = al[hb + b];
-                double di = a - sig;
-                if (i > 0) {
-                    const double l = bprev * qd_rcp(d);
-                    di = di - l * bprev;
-                    W.lf[hb + b] = l;
-                }
-                if (!(di > tiny)) di = tiny;
-                d = di;
-                W.rd[hb + b] = qd_rcp(d);
-                bprev = be[hb + b];
-            }
+#define QD_FAC_ROW(SLOT, FIRST)                                                     \
+        {                                                                           \
+            double di_ = al[SLOT] - sig;                                            \
+            if (!(FIRST)) { const double l_ = bprev * qd_rcp(d); di_ = di_ - l_ * bprev; W.lf[SLOT] = l_; } \
+            if (!(di_ > tiny)) di_ = tiny;                                          \
+            d = di_;                                                                \
+            W.rd[SLOT] = qd_rcp(d);                                                 \
+            bprev = be[SLOT];                                                       \
         }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) if (i < k) QD_FAC_ROW(MB.idx[i], i == 0)
+        {
+            unsigned mm = MB.rest;
+            for (int i = 8; i < kmax; ++i) if (i < k) { const int b = hb + __builtin_ctz(mm); mm &= mm - 1; QD_FAC_ROW(b, false) }
+        }
+#undef QD_FAC_ROW
         __builtin_amdgcn_wave_barrier();
         for (int iter = 0; iter < 2; ++iter) {
             // forward  L z = rhs, then w = D^-1 z
-            unsigned m2 = seg;
             double zprev = 0.0;
-            for (int i = 0; i < kmax; ++i) {
-                if (i < k) {
-                    const int b = __builtin_ctz(m2); m2 &= m2 - 1;
-                    const double rhs = (iter == 0) ? 1.0 : W.yv[hb + b];
-                    const double z = (i == 0) ? rhs : rhs - W.lf[hb + b] * zprev;
-                    W.yv[hb + b] = z * W.rd[hb + b];
-                    zprev = z;
-                }
+#define QD_FWD_ROW(SLOT, FIRST)                                                     \
+            {                                                                       \
+                const double rhs_ = (iter == 0) ? 1.0 : W.yv[SLOT];                 \
+                const double z_ = (FIRST) ? rhs_ : rhs_ - W.lf[SLOT] * zprev;       \
+                W.yv[SLOT] = z_ * W.rd[SLOT];                                       \
+                zprev = z_;                                                         \
             }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) if (i < k) QD_FWD_ROW(MB.idx[i], i == 0)
+            {
+                unsigned mm = MB.rest;
+                for (int i = 8; i < kmax; ++i) if (i < k) { const int b = hb + __builtin_ctz(mm); mm &= mm - 1; QD_FWD_ROW(b, false) }
+            }
+#undef QD_FWD_ROW
             __builtin_amdgcn_wave_barrier();
-            // backward  L^T y = w : y_i = w_i - l_i y_{i+1}; walk the first k members from the top
-            unsigned m3 = seg;
-            for (int i = ssz; i > k; --i) m3 &= ~(1u << (31 - __builtin_clz(m3)));
+            // backward  L^T y = w : y_i = w_i - l_i y_{i+1}; rows k-1 .. 0
             double ynext = 0.0, lnext = 0.0, nrm = 0.0;
-            for (int i = kmax - 1; i >= 0; --i) {
-                if (i < k) {
-                    const int b = 31 - __builtin_clz(m3); m3 &= ~(1u << b);
-                    const double y = W.yv[hb + b] - lnext * ynext;      // lnext = l_i (0 for the last row)
-                    W.yv[hb + b] = y;
-                    nrm = fma(y, y, nrm);
-                    ynext = y;
-                    lnext = (i > 0) ? W.lf[hb + b] : 0.0;               // l_{i-1}
-                }
+#define QD_BWD_ROW(SLOT, IDX)                                                       \
+            {                                                                       \
+                const double y_ = W.yv[SLOT] - lnext * ynext;   /* lnext = l_i (0 for the last row) */ \
+                W.yv[SLOT] = y_;                                                    \
+                nrm = fma(y_, y_, nrm);                                             \
+                ynext = y_;                                                         \
+                lnext = ((IDX) > 0) ? W.lf[SLOT] : 0.0;          /* l_{i-1} */      \
             }
+            {
+                // rows >= 8 first (descending), dropping member bits beyond row k-1
+                unsigned m3 = MB.rest;
+                for (int i = ssz; i > k && i > 8; --i) m3 &= ~(1u << (31 - __builtin_clz(m3)));
+                for (int i = kmax - 1; i >= 8; --i) if (i < k) { const int b = 31 - __builtin_clz(m3); m3 &= ~(1u << b); QD_BWD_ROW(hb + b, i) }
+            }
+#pragma unroll
+            for (int i = 7; i >= 0; --i) if (i < k) QD_BWD_ROW(MB.idx[i], i)
+#undef QD_BWD_ROW
             __builtin_amdgcn_wave_barrier();
             const double inv = (nrm > 0.0) ? 1.0 / sqrt(nrm) : 1.0;
-            unsigned m4 = seg;
-            for (int i = 0; i < kmax; ++i) {
-                if (i < k) { const int b = __builtin_ctz(m4); m4 &= m4 - 1; W.yv[hb + b] = W.yv[hb + b] * inv; }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) if (i < k) W.yv[MB.idx[i]] = W.yv[MB.idx[i]] * inv;
+            {
+                unsigned mm = MB.rest;
+                for (int i = 8; i < kmax; ++i) if (i < k) { const int b = hb + __builtin_ctz(mm); mm &= mm - 1; W.yv[b] = W.yv[b] * inv; }
             }
             __builtin_amdgcn_wave_barrier();
         }
@@ -498,7 +528,10 @@ __device__ void qd_ground_pixel(const double* __restrict__ A, const QdPixelRec* 
             double yj = 0.0, a = 0.0, b = 0.0, ib = 0.0;
             if (!done2) { const int bb = __builtin_ctz(mm); mm &= mm - 1; yj = W.yv[hb + bb]; a = al[hb + bb]; b = be[hb + bb]; ib = W.ib[hb + bb]; }
             double w = F * q2;
-            for (int s = 0; s < maxcnt; ++s) {
+#pragma unroll
+            for (int i = 0; i < QD_NBREG; ++i)
+                if (i < maxcnt) { const double qj = __shfl(q2, nbi[i], 32); w = fma(nbc[i], qj, w); }
+            for (int s = QD_NBREG; s < maxcnt; ++s) {
                 const double qj = __shfl(q2, (int)W.nidx[s][lane], 32);
                 w = fma(W.coef[s][lane], qj, w);
             }

@@ -172,8 +172,11 @@ qd_k_candidates(const int* __restrict__ env_ids, int env_base, int R, const doub
 #define QD_GS_BLOCK 256
 #define QD_GS_PPB 64            // pixels per block: 8 half-waves x 8 pixels
 
+#ifndef QD_GS_WAVES
+#define QD_GS_WAVES 3
+#endif
 template <int N>
-__global__ void __launch_bounds__(QD_GS_BLOCK)
+__global__ void __launch_bounds__(QD_GS_BLOCK, QD_GS_WAVES)
 qd_k_ground(const int* __restrict__ env_ids, int env_base, int R, const double* __restrict__ params,
             const QdPixelRec* __restrict__ recs, double* __restrict__ zraw, double* __restrict__ occ_out,
             const double* __restrict__ state, int noise_flags) {
