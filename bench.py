@@ -82,6 +82,7 @@ def main():
     ap.add_argument("--resolution", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--noise", action="store_true", help="all stochastic stages on (throughput only)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -101,7 +102,7 @@ def main():
     from qadapt_hip import shard as _shard
     first_env, _ = _shard.shard_env_ids(rank, world, B)
     env = VecQuantumDeviceEnv(B, num_dots=N, resolution=R, device=dev, seed=1234, env_id_offset=first_env,
-                              capacitance_model=SyntheticCapacitanceModel(99 + rank))
+                              capacitance_model=SyntheticCapacitanceModel(99 + rank), noise=True if args.noise else None)
     gen = torch.Generator(device="cpu").manual_seed(99 + rank)
     env.reset()
 
@@ -129,24 +130,33 @@ def main():
     if rank == 0:
         total_env_steps = B * world * args.steps
         value = total_env_steps / dt
-        # dominant kernel: ground state (one launch covers `chunk` envs); HIP events inside the library
+        # dominant kernel: ground state (one launch covers `chunk` envs); HIP events inside the library,
+        # on the stream the kernels are launched on
         gs_ms = env.time_ground_kernel(iters=2)
-        import ctypes
+        cand_ms = env.time_candidates_kernel(iters=2)
         chunk = min(B, max(1, (1 << 30) // ((N - 1) * R * R * 216)))
         alg_bytes = b_alg(N, R) * chunk
         achieved = alg_bytes / (gs_ms * 1e-3) / 1e9
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")     # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+        if os.path.exists(tfile):
+            t = json.load(open(tfile)).get(f"ground_{N}dot_{R}", None)
+            if t:
+                traffic = t["bytes_per_env_step"] * chunk
         out = {
             "metric": "env steps/sec (batched 8-dot 64x64 CSD solves)" if (N, R) == (8, 64) else f"env steps/sec ({N}-dot {R}x{R} CSD solves)",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{N}-dot array, {B} parallel envs per GPU, {R}x{R} CSD, deterministic physics "
-                                   f"(latching/noise off), 50-step episodes with auto-reset, synthetic CNN outputs",
+            "config": {"workload": f"{N}-dot array, {B} parallel envs per GPU, {R}x{R} CSD, "
+                                   + ("all stochastic stages on" if args.noise else "deterministic physics (latching/noise off)")
+                                   + ", 50-step episodes with auto-reset, synthetic CNN outputs",
                        "n_dots": N, "envs_per_gpu": B, "resolution": R, "pixels_per_s": value * (N - 1) * R * R},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": f"qd_k_ground<{N}>", "kernel_ms": gs_ms, "envs_per_launch": chunk,
                          "algorithmic_bytes_per_env_step": b_alg(N, R),
+                         "second_kernel": f"qd_k_candidates<{N}>", "second_kernel_ms": cand_ms,
                          "note": "the faithful path is float64 VALU/LDS bound, not HBM bound (SURVEY 7-H1); "
                                  "the HBM fraction is reported as the contract asks, see DESIGN.md"},
         }
