@@ -322,3 +322,104 @@ def test_product_mode_equals_validate_mode(N, R):
         env.close()
     assert np.allclose(outs[0][0], outs[1][0], rtol=1e-9, atol=1e-12)
     assert np.abs(outs[0][1] - outs[1][1]).max() <= 1e-6
+
+
+@pytest.mark.parametrize("N,R", [(2, 10), (4, 9), (3, 100)])
+def test_odd_resolutions(N, R):
+    """Resolutions that are not multiples of the 8x8 search tile or of the 64-pixel ground-state
+    block (the reference default is 100): every pixel is produced exactly once."""
+    B = 2
+    env = _env(B, N, R)
+    env.reset()
+    st, steps = env.get_state()
+    rng = np.random.default_rng(3)
+    for e in range(B):
+        st[e] = H.place(N, st[e], "near", rng)
+    env.set_state(st, steps)
+    from qadapt_hip import _lib
+    _lib.check(env._h, env._lib.qd_observe(env._h, None, 0, env._stream()), "qd_observe")
+    raw, plohi = env.raw()
+    cand = env.candidates()
+    e = 1
+    dev = H.dev_view(N, env._params_host[e]); sv = H.state_view(N, st[e])
+    for ch in sorted({0, N - 2}):
+        ref = OC.csd_channel(dev, sv.vgm, dev.origin, sv.gate_v, sv.sensor_gt, sv.barrier_v, dev.window, ch, R)
+        assert np.array_equal(cand[e, ch], ref["states"])
+        assert np.allclose(raw[e, ch], ref["z"], rtol=1e-6, atol=1e-9)
+    img = env.global_image.cpu().numpy()
+    assert np.array_equal(img[e], O.normalise_image(raw[e].reshape(N - 1, R, R).transpose(1, 2, 0)))
+    env.close()
+
+
+def test_full_size_properties_8dot_64():
+    """BASELINE config shape (8 dots, 64x64) on a batch too large for the oracle: size-independent
+    properties.  (1) the float32 image is exactly numpy's percentile normalisation of the raw signal;
+    (2) hopping conserves charge: total occupation is an integer; (3) occupations lie inside the kept
+    candidates' range; (4) per-agent tensors are the documented views of the global image;
+    (5) a second observe of the same state is bit-identical (no hidden state, no races)."""
+    N, R, B = 8, 64, 24
+    env = _env(B, N, R)
+    env.reset()
+    st, steps = env.get_state()
+    rng = np.random.default_rng(11)
+    for e in range(B):
+        st[e] = H.place(N, st[e], ("near", "mid")[e % 2], rng)
+    env.set_state(st, steps)
+    from qadapt_hip import _lib
+    _lib.check(env._h, env._lib.qd_observe(env._h, None, 0, env._stream()), "qd_observe")
+    raw, plohi = env.raw()
+    img = env.global_image.cpu().numpy()
+    occ = env.occupations(); cand = env.candidates()
+    for e in range(B):
+        assert plohi[e, 0] == np.percentile(raw[e], 0.5) and plohi[e, 1] == np.percentile(raw[e], 99.5)
+        assert np.array_equal(img[e], O.normalise_image(raw[e].reshape(N - 1, R, R).transpose(1, 2, 0)))
+    tot = occ.sum(axis=-1)
+    assert np.mean(np.abs(tot - np.round(tot)) < 1e-6) > 0.995
+    assert np.all(occ >= cand.min(axis=3) - 1e-9) and np.all(occ <= cand.max(axis=3) + 1e-9)
+    assert np.all(cand >= 0)
+    pim = env.plunger_images.cpu().numpy(); bim = env.barrier_images.cpu().numpy()
+    for e in (0, B - 1):
+        ag = O.agent_images(img[e], N)
+        for i in range(N):
+            assert np.array_equal(pim[e, i], ag[f"plunger_{i}"])
+        for j in range(N - 1):
+            assert np.array_equal(bim[e, j], ag[f"barrier_{j}"])
+    _lib.check(env._h, env._lib.qd_observe(env._h, None, 0, env._stream()), "qd_observe")
+    raw2, _ = env.raw()
+    assert np.array_equal(raw, raw2)
+    env.close()
+
+
+def test_mirror_symmetric_device_gives_symmetric_csd():
+    """SURVEY known answer (5): a device that is symmetric under dot exchange scanned at symmetric
+    voltages gives CSD(x,y) == CSD(y,x) -- checks pixel order / transposes end to end on the GPU."""
+    N, R, B = 2, 24, 1
+    env = _env(B, N, R)
+    env.reset()
+    L = env.L; G = N + 1
+    Cdd = np.array([[0, 0.1], [0.1, 0]]); Cgd = np.array([[1.0, 0.4, 0.0], [0.4, 1.0, 0.0]])
+    dev = O.Device(Cdd, Cgd, [[0.04, 0.04]], [[0.0, 0.0, 1.0]], [[0.05], [0.05]], [[0.1, 0.1, 0.05]],
+                   [[0.0005]], [[1.0]], 1.0, [1.2], 0.1)
+    par = env.last_episode.params[0].copy(); stt = env.last_episode.state[0].copy()
+    par[L.cdd_inv:L.cdd_inv + G * G] = dev.cdd_inv_full.reshape(-1)
+    par[L.cgd:L.cgd + G * 2 * N] = dev.cgd_full.reshape(-1)
+    par[L.cbg:L.cbg + (N - 1) * G] = dev.Cbg.reshape(-1)
+    A = dev.cdd_inv_full[:N, :N]
+    U = np.linalg.cholesky(A[::-1, ::-1])[::-1, ::-1]
+    par[L.ufac:L.ufac + N * N] = U.reshape(-1); par[L.uinv:L.uinv + N] = 1 / np.diag(U)
+    par[L.alpha] = 1.2; par[L.scal] = 1.0; par[L.scal + 1] = 0.1; par[L.scal + 2] = 1.7
+    par[L.origin:L.origin + G] = 0
+    stt[L.s_vgm:L.s_vgm + G * G] = (-np.eye(G)).reshape(-1)
+    stt[L.s_gate_v:L.s_gate_v + N] = 0.7; stt[L.s_barrier_v] = 5.0; stt[L.s_sensor_gt] = 0.5
+    import ctypes
+    from qadapt_hip import _lib
+    ids = np.array([0], np.int32)
+    _lib.check(env._h, env._lib.qd_load_episodes(env._h, ids.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), 1,
+                                                 par[None].ctypes.data, stt[None].ctypes.data, 0, env._stream()), "load")
+    _lib.check(env._h, env._lib.qd_observe(env._h, None, 0, env._stream()), "observe")
+    raw, _ = env.raw()
+    z = raw[0, 0].reshape(R, R)
+    assert np.allclose(z, z.T, rtol=1e-9, atol=1e-12)
+    ref = O.get_obs_images(dev, O.identity_vgm(N), np.zeros(3), np.array([0.7, 0.7]), np.array([5.0]), 0.5, 1.7, R)
+    assert np.allclose(z, ref[:, :, 0], rtol=1e-6, atol=1e-9)
+    env.close()
