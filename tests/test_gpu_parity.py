@@ -423,3 +423,24 @@ def test_mirror_symmetric_device_gives_symmetric_csd():
     ref = O.get_obs_images(dev, O.identity_vgm(N), np.zeros(3), np.array([0.7, 0.7]), np.array([5.0]), 0.5, 1.7, R)
     assert np.allclose(z, ref[:, :, 0], rtol=1e-6, atol=1e-9)
     env.close()
+
+
+def test_mixed_dot_counts_bucketed():
+    """Config 5 (ragged N in {2,4,6,8}): bucketed by N; each bucket equals a homogeneous env with
+    the same global ids."""
+    import torch
+    from qadapt_hip.mixed import MixedVecQuantumDeviceEnv
+    from qadapt_hip.vec_env import VecQuantumDeviceEnv, SyntheticCapacitanceModel
+    counts = {2: 2, 4: 2, 6: 1, 8: 1}
+    R = 16
+    mix = MixedVecQuantumDeviceEnv(counts, resolution=R, seed=50, capacitance_model_factory=lambda n: SyntheticCapacitanceModel(n))
+    obs = mix.reset()
+    assert set(obs) == {2, 4, 6, 8} and obs[6]["image"].shape == (1, R, R, 5)
+    acts = {n: torch.zeros((c, 2 * n - 1), device="cuda") for n, c in counts.items()}
+    out = mix.step(acts)
+    solo = VecQuantumDeviceEnv(2, num_dots=4, resolution=R, seed=50, env_id_offset=2,
+                               capacitance_model=SyntheticCapacitanceModel(4))
+    solo.reset()
+    o2, r2, _, _ = solo.step(acts[4])
+    assert torch.equal(out[4][0]["image"], o2["image"]) and torch.equal(out[4][1], r2)
+    mix.close(); solo.close()
