@@ -82,19 +82,22 @@ def main():
     ap.add_argument("--resolution", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend for the barrier / max-time reduction (gloo: rehearsal of N>1 on one GPU)")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: all ranks use cuda:0")
     ap.add_argument("--noise", action="store_true", help="all stochastic stages on (throughput only)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.share_gpu:
+        local = 0
     if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+        from qadapt_hip import shard as _sh
+        dist = _sh.init(args.backend, local)
     else:
         dist = None
-        torch.cuda.set_device(0)
+    torch.cuda.set_device(local)
     from qadapt_hip.vec_env import VecQuantumDeviceEnv, SyntheticCapacitanceModel
 
     N, R, B = args.dots, args.resolution, args.envs
@@ -125,7 +128,7 @@ def main():
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
     from qadapt_hip import shard
-    dt = shard.max_over_ranks(dt, device=dev)          # identity when not distributed
+    dt = shard.max_over_ranks(dt, device=dev if args.backend == "nccl" else None)   # identity when not distributed
 
     if rank == 0:
         total_env_steps = B * world * args.steps
