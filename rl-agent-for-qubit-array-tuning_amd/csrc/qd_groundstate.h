@@ -40,8 +40,8 @@
 #endif
 
 struct QdWaveLds {
-    double coef[QD_NBMAX][64];      // H_ij of neighbour slot s of lane
-    unsigned char nidx[QD_NBMAX][64];
+    double coef[QD_NBMAX - QD_NBREG][64];      // H_ij of neighbour slots QD_NBREG.. of lane (the first QD_NBREG live in registers)
+    unsigned char nidx[QD_NBMAX - QD_NBREG][64];
     double buf[66];                 // publish buffer for per-component reductions; buf[64] == 0.0 (neutral slot)
     double al[64], be[64];          // T: alpha_r / beta_r at the r-th member lane
     double rd[64], lf[64], yv[64];  // inverse iteration: 1/d_i, l_i, y_i at member slots
@@ -225,6 +225,10 @@ __device__ void qd_ground_pixel(const double* __restrict__ A, const QdPixelRec* 
 #endif
     const int cnt = __popc(nbrmask);
     const int maxcnt = qd_wave_max_int(cnt);
+    // the first QD_NBREG neighbour slots stay in registers for the matvecs, the rest in LDS
+    double nbc[QD_NBREG + 1]; int nbi[QD_NBREG + 1];
+#pragma unroll
+    for (int i = 0; i < QD_NBREG; ++i) { nbc[i] = 0.0; nbi[i] = m; }
     {
         unsigned rem = nbrmask;
         for (int s = 0; s < maxcnt; ++s) {
@@ -247,17 +251,10 @@ __device__ void qd_ground_pixel(const double* __restrict__ A, const QdPixelRec* 
                                             : (double)nd1 * ((double)nd + 1.0);
                 c = -t * sqrt(prod);
             }
-            W.coef[s][lane] = c;
-            W.nidx[s][lane] = (unsigned char)j;
-        }
-    }
-
-    // the first 6 neighbour slots stay in registers for the matvecs (typical degree <= 6)
-    double nbc[QD_NBREG + 1]; int nbi[QD_NBREG + 1];
 #pragma unroll
-    for (int i = 0; i < QD_NBREG; ++i) {
-        nbc[i] = (i < maxcnt) ? W.coef[i][lane] : 0.0;
-        nbi[i] = (i < maxcnt) ? (int)W.nidx[i][lane] : m;
+            for (int i = 0; i < QD_NBREG; ++i) if (i == s) { nbc[i] = c; nbi[i] = j; }
+            if (s >= QD_NBREG) { W.coef[s - QD_NBREG][lane] = c; W.nidx[s - QD_NBREG][lane] = (unsigned char)j; }
+        }
     }
 
     // ---- 3. connected components (reach masks) -----------------------------
@@ -269,7 +266,7 @@ __device__ void qd_ground_pixel(const double* __restrict__ A, const QdPixelRec* 
         for (int i = 0; i < QD_NBREG; ++i)
             if (i < maxcnt) { const unsigned r2 = __shfl(seg, nbi[i], 32); if (i < cnt) nw |= r2; }
         for (int s = QD_NBREG; s < maxcnt; ++s) {
-            const unsigned r2 = __shfl(seg, (int)W.nidx[s][lane], 32);
+            const unsigned r2 = __shfl(seg, (int)W.nidx[s - QD_NBREG][lane], 32);
             if (s < cnt) nw |= r2;
         }
         const bool changed = nw != seg;
@@ -293,7 +290,9 @@ __device__ void qd_ground_pixel(const double* __restrict__ A, const QdPixelRec* 
 
     // ---- 4. Gershgorin pruning ---------------------------------------------
     double radius = 0.0;
-    for (int s = 0; s < maxcnt; ++s) radius += fabs(W.coef[s][lane]);
+#pragma unroll
+    for (int i = 0; i < QD_NBREG; ++i) radius += fabs(nbc[i]);
+    for (int s = QD_NBREG; s < maxcnt; ++s) radius += fabs(W.coef[s - QD_NBREG][lane]);
     const double upper_all = qd_half_min(F);
     const double comp_lower = qd_seg_min(F - radius, MB, ssz, buf, hb);
     const bool active = comp_lower <= upper_all;
@@ -317,8 +316,8 @@ __device__ void qd_ground_pixel(const double* __restrict__ A, const QdPixelRec* 
         for (int i = 0; i < QD_NBREG; ++i)
             if (i < maxcnt) { const double qj = __shfl(q, nbi[i], 32); w = fma(nbc[i], qj, w); }
         for (int s = QD_NBREG; s < maxcnt; ++s) {
-            const double qj = __shfl(q, (int)W.nidx[s][lane], 32);
-            w = fma(W.coef[s][lane], qj, w);
+            const double qj = __shfl(q, (int)W.nidx[s - QD_NBREG][lane], 32);
+            w = fma(W.coef[s - QD_NBREG][lane], qj, w);
         }
         const double a = qd_seg_sum(q * w, MB, buf, hb);
         w = w - a * q - bp * qp;
@@ -532,8 +531,8 @@ __device__ void qd_ground_pixel(const double* __restrict__ A, const QdPixelRec* 
             for (int i = 0; i < QD_NBREG; ++i)
                 if (i < maxcnt) { const double qj = __shfl(q2, nbi[i], 32); w = fma(nbc[i], qj, w); }
             for (int s = QD_NBREG; s < maxcnt; ++s) {
-                const double qj = __shfl(q2, (int)W.nidx[s][lane], 32);
-                w = fma(W.coef[s][lane], qj, w);
+                const double qj = __shfl(q2, (int)W.nidx[s - QD_NBREG][lane], 32);
+                w = fma(W.coef[s - QD_NBREG][lane], qj, w);
             }
             w = w - a * q2 - bp2 * qp2;
             if (!done2) {
