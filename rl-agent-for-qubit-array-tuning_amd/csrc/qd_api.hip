@@ -19,7 +19,6 @@ struct qd_handle {
     int* steps;
     QdPixelRec* recs;
     size_t recs_envs;                       // envs the recs buffer holds
-    int* rec_env_of_slot;                   // validate mode: recs are stored per env id
     float *gimg, *pimg, *bimg, *volt;
     unsigned long long* tel; int tel_words;
     unsigned long long obs_serial;
@@ -124,9 +123,9 @@ extern "C" int qd_create(const qd_config* cfg, int device, qd_handle** out) {
 
 extern "C" int qd_destroy(qd_handle* h) {
     if (!h) return QD_ERR_ARG;
-    hipSetDevice(h->device);
-    hipFree(h->params); hipFree(h->state); hipFree(h->steps); hipFree(h->zraw); hipFree(h->plohi);
-    hipFree(h->recs); if (h->occ) hipFree(h->occ); if (h->tel) hipFree(h->tel);
+    (void)hipSetDevice(h->device);
+    void* bufs[] = {h->params, h->state, h->steps, h->zraw, h->plohi, h->recs, h->occ, h->tel};
+    for (void* b : bufs) if (b) (void)hipFree(b);
     delete h;
     return QD_OK;
 }
@@ -352,7 +351,7 @@ extern "C" int qd_time_ground_kernel(qd_handle* h, int iters, float* mean_ms, vo
     QD_HIP(hipEventSynchronize(b));
     float ms = 0.f;
     QD_HIP(hipEventElapsedTime(&ms, a, b));
-    hipEventDestroy(a); hipEventDestroy(b);
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
     *mean_ms = ms / iters;
     return QD_OK;
 }
@@ -376,7 +375,7 @@ extern "C" int qd_time_candidates_kernel(qd_handle* h, int iters, float* mean_ms
     QD_HIP(hipEventSynchronize(b));
     float ms = 0.f;
     QD_HIP(hipEventElapsedTime(&ms, a, b));
-    hipEventDestroy(a); hipEventDestroy(b);
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
     *mean_ms = ms / iters;
     return QD_OK;
 }

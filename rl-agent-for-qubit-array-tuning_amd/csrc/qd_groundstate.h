@@ -22,10 +22,11 @@
 //      (H_t <= 0 off-diagonal => the ground vector of an irreducible block is
 //      positive, so the start vector always overlaps it); at most `size` steps.
 //      The tridiagonal T lives one row per member lane.
-//   6. lowest eigenvalue of T by multisection on the Sturm count (each member
-//      lane tests its own shift), eigenvector of T by inverse iteration with
-//      the SPD factorisation at the lower bracket end.
-//   7. second Lanczos pass accumulates x = Q y (no basis storage).
+//   6. lowest eigenvalue of T by Laguerre's iteration from the left of the
+//      spectrum (monotone, cubic), eigenvector of T by inverse iteration with the
+//      SPD factorisation just below it.
+//   7. second Lanczos pass accumulates x = Q y (no basis storage); it replays the
+//      recurrence with the stored alpha/beta, so it needs no reductions.
 //   8. the component with the lowest eigenvalue wins; <n> = sum_m x_m^2 s_m.
 // Solving block by block is at least as accurate as one dense 32x32 eigh (no
 // rounding-level mixing of different charge sectors).
@@ -126,35 +127,6 @@ __device__ __forceinline__ double qd_seg_min(double v, const QdMembers& M, int s
 }
 __device__ __forceinline__ double qd_seg_max(double v, const QdMembers& M, int ssz, volatile double* buf, int hb) {
     return -qd_seg_min(-v, M, ssz, buf, hb);
-}
-
-// Sturm count (number of eigenvalues < lam) of the k x k tridiagonal whose rows
-// live at the member lanes of `seg` (ascending order).  Division-free: sign
-// changes of the leading-minor polynomials p_i = (a_i - lam) p_{i-1} - b_{i-1}^2 p_{i-2}
-// (one dependent fma per row), rescaled to stay inside the float64 range.
-__device__ __forceinline__ int qd_sturm(double lam, unsigned seg, int k, int kmax,
-                                        volatile const double* al, volatile const double* be, int hb) {
-    unsigned mm = seg;
-    int cnt = 0;
-    double p = 1.0, pm = 0.0, bprev = 0.0;
-    bool neg = false;
-    for (int i = 0; i < kmax; ++i) {
-        if (i < k) {
-            const int b = __builtin_ctz(mm); mm &= mm - 1;
-            const double a = al[hb + b];
-            const double u = (bprev * bprev) * pm;
-            double pn = fma(a - lam, p, -u);
-            const bool nneg = (pn == 0.0) ? !neg : (pn < 0.0);
-            cnt += nneg != neg;
-            neg = nneg;
-            pm = p; p = pn;
-            const double ap = fabs(p);
-            if (ap > 1e100) { p *= 1e-100; pm *= 1e-100; }
-            else if (ap < 1e-100 && ap > 0.0) { p *= 1e100; pm *= 1e100; }
-            bprev = be[hb + b];
-        }
-    }
-    return cnt;
 }
 
 // One pixel per half-wave.  A: cdd_inv (row-major, lda = N+1) readable by all

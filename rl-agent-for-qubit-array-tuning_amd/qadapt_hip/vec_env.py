@@ -24,14 +24,6 @@ from .device_model import DeviceSampler, load_yaml
 from .layout import layout
 
 
-class _DevPtr:
-    """Zero-copy torch view over library-owned device memory."""
-
-    def __init__(self, ptr, shape, typestr):
-        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr,
-                                         "data": (int(ptr), False), "version": 2}
-
-
 class SyntheticCapacitanceModel:
     """Stand-in for the capacitance CNN used by benchmarks and tests
     (values ~ N(0, 0.1^2), log_vars ~ U(-6, -2)); deterministic
