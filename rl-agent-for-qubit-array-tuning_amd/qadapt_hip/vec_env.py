@@ -165,12 +165,10 @@ class VecQuantumDeviceEnv:
         return fv, fl
 
     # ------------------------------------------------------------------ reset
-    def reset(self, env_ids=None, seed=None, options=None, cnn_outputs=None):
-        """Reset the listed envs (all if None).  Returns the observation dict of
-        the whole batch (device tensors, valid until the next call)."""
+    def load_new_devices(self, env_ids=None, seed=None):
+        """Sample new random devices for the listed envs and upload their parameter / initial
+        state blocks (the device-construction half of reset(); no observation is rendered)."""
         ids = np.arange(self.B, dtype=np.int32) if env_ids is None else np.asarray(env_ids, dtype=np.int32).reshape(-1)
-        if ids.size == 0:
-            return self._obs()
         if seed is not None:
             for e in ids:
                 self._rngs[e] = np.random.Generator(np.random.PCG64(int(seed) + int(e)))
@@ -182,6 +180,22 @@ class VecQuantumDeviceEnv:
         rc = self._lib.qd_load_episodes(self._h, ip, int(ids.size), eb.params.ctypes.data, eb.state.ctypes.data,
                                         1 if self.reset_kalman_on_reset else 0, self._stream())
         _lib.check(self._h, rc, "qd_load_episodes")
+        self._needs_reset = False
+        return eb
+
+    def observe(self, env_ids_dev=None, n=0):
+        """Render the observation of the current state (qd_observe) without stepping."""
+        idp = None if env_ids_dev is None else ctypes.c_void_p(env_ids_dev.data_ptr())
+        _lib.check(self._h, self._lib.qd_observe(self._h, idp, int(n), self._stream()), "qd_observe")
+        return self._obs()
+
+    def reset(self, env_ids=None, seed=None, options=None, cnn_outputs=None):
+        """Reset the listed envs (all if None).  Returns the observation dict of
+        the whole batch (device tensors, valid until the next call)."""
+        ids = np.arange(self.B, dtype=np.int32) if env_ids is None else np.asarray(env_ids, dtype=np.int32).reshape(-1)
+        if ids.size == 0:
+            return self._obs()
+        self.load_new_devices(ids, seed=seed)
         all_envs = ids.size == self.B and np.array_equal(ids, np.arange(self.B))
         ids_dev = None if all_envs else torch.as_tensor(ids, dtype=torch.int32, device=self.device)
         idp = None if all_envs else ctypes.c_void_p(ids_dev.data_ptr())

@@ -444,3 +444,40 @@ def test_mixed_dot_counts_bucketed():
     o2, r2, _, _ = solo.step(acts[4])
     assert torch.equal(out[4][0]["image"], o2["image"]) and torch.equal(out[4][1], r2)
     mix.close(); solo.close()
+
+
+def test_dataset_generator_format_and_values(tmp_path):
+    """bulk dataset generation on the batched kernels.  On-disk layout as the
+    reference's dataloader globs it; images (noise off) equal the oracle's _get_obs for the same
+    device / VGM / voltages."""
+    import json, glob, os
+    from qadapt_hip.dataset import GenerationConfig, SymmetricCapacitanceGenerator, sample_targets
+    N, R = 4, 16
+    cfg = GenerationConfig(total_samples=5, num_dots=N, output_dir=str(tmp_path), batch_size=3, seed_base=7,
+                           resolution=R, noise=False)
+    gen = SymmetricCapacitanceGenerator(cfg)
+    assert gen.run() == 5
+    imgs = sorted(glob.glob(os.path.join(str(tmp_path), "images", "batch_*.npy")))
+    cgds = sorted(glob.glob(os.path.join(str(tmp_path), "cgd_matrices", "batch_*.npy")))
+    assert [os.path.basename(p) for p in imgs] == ["batch_000.npy", "batch_001.npy"] and len(cgds) == 2
+    a = np.load(imgs[0]); c = np.load(cgds[0]); b = np.load(imgs[1])
+    assert a.shape == (3, R, R, N - 1) and a.dtype == np.float32 and b.shape == (2, R, R, N - 1)
+    assert c.shape == (3, N, N + 1) and c.dtype == np.float32
+    assert np.all(np.diag(c[0][:, :N]) == 1) and np.allclose(c[0][:, :N], c[0][:, :N].T) and np.all(c[:, :, N] == 0)
+    gtj = json.load(open(os.path.join(str(tmp_path), "ground_truth", "batch_000.json")))
+    assert len(gtj) == 3 and set(gtj[0]) == {"ground_truth_voltages", "gate_voltages", "sample_id"}
+    assert os.path.exists(os.path.join(str(tmp_path), "metadata", "dataset_info.json"))
+    # values: re-render the last batch and compare sample 0 of it with the oracle
+    images, labels, gt, gate_v = gen.render_batch([3, 4])
+    env = gen.env; L = env.L; G = N + 1
+    st, _ = env.get_state()
+    dev = H.dev_view(N, env._params_host[0]); sv = H.state_view(N, st[0])
+    assert np.allclose(sv.gate_v, gate_v[0])
+    # effective coupling realised by the VGM equals the sampled target (qarray_base_class.py:948-989)
+    T, lab, _ = sample_targets(cfg, [3])
+    eff = dev.cdd_inv_full @ dev.cgd_full[:, :G] @ sv.vgm
+    assert np.allclose(eff[:N, :N], T[0], atol=1e-9)
+    ref = O.get_obs_images(dev, sv.vgm, dev.origin, sv.gate_v, sv.barrier_v, 0.0, dev.window, R)
+    ok = np.abs(images[0] - ref) <= 1e-5 * (1 + np.abs(ref))
+    assert ok.mean() > 0.99
+    gen.close()
