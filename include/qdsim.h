@@ -42,6 +42,8 @@ extern "C" {
                                  (TunnelCoupledChargeSensed.py:354; qarray WhiteNoise/TelegraphNoise) */
 #define QD_NOISE_RADIAL 2     /* distance-dependent image noise / white-noise replacement
                                  (qarray_base_class.py:444-493)                     */
+#define QD_NOISE_LATCH 4      /* charge latching along the raster (ground_state.py:164; qarray
+                                 LatchingModel, source absent: UNVERIFIED restatement)     */
 
 typedef struct qd_handle qd_handle;
 
@@ -72,8 +74,8 @@ typedef struct qd_config {
  * layout is documented in csrc/qd_common.h (mirrored by qadapt_hip/layout.py). */
 int qd_param_block_doubles(int n_dot);
 int qd_state_block_doubles(int n_dot);
-/* Writes the 29 layout integers (see qadapt_hip/layout.py LAYOUT_FIELDS). */
-int qd_layout_query(int n_dot, int32_t* out29);
+/* Writes the 31 layout integers (see qadapt_hip/layout.py LAYOUT_FIELDS). */
+int qd_layout_query(int n_dot, int32_t* out31);
 
 /* QuantumDeviceEnv.__init__ (env.py:38-132): allocates device state for B envs
  * on GPU `device`; Kalman filters start at their priors (env.py:779-787). */

@@ -90,7 +90,7 @@ extern "C" int qd_create(const qd_config* cfg, int device, qd_handle** out) {
         QD_HIP(hipMalloc(&h->tel, sizeof(unsigned long long) * (size_t)h->B * h->C * h->tel_words));
         QD_HIP(hipMemset(h->tel, 0, sizeof(unsigned long long) * (size_t)h->B * h->C * h->tel_words));
     }
-    if (cfg->flags & QD_FLAG_VALIDATE)
+    if ((cfg->flags & QD_FLAG_VALIDATE) || (cfg->noise_flags & QD_NOISE_LATCH))
         QD_HIP(hipMalloc(&h->occ, sizeof(double) * (size_t)h->B * h->C * h->P * h->N));
     QD_HIP(hipMemset(h->params, 0, sizeof(double) * (size_t)h->B * h->L.size));
     QD_HIP(hipMemset(h->steps, 0, sizeof(int) * (size_t)h->B));
@@ -243,6 +243,11 @@ extern "C" int qd_observe(qd_handle* h, const int32_t* env_ids, int n, void* str
         QD_HIP(hipGetLastError());
         int rc = qd_launch_ground(h, env_ids, base, cnt, s);
         if (rc) return rc;
+    }
+    if (h->cfg.noise_flags & QD_NOISE_LATCH) {
+        const int nt = n * h->C;
+        QD_DISPATCH_N(h->N, qd_k_latch<NN><<<dim3((nt + 63) / 64), dim3(64), 0, s>>>(env_ids, n, h->R, h->params, h->state, h->occ, h->zraw, qd_noise_cfg(h)));
+        QD_HIP(hipGetLastError());
     }
     {
         dim3 g3((h->P + 255) / 256, h->C, n);

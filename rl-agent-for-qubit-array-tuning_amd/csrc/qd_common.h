@@ -35,9 +35,11 @@
 //   tc_base, gamma, window, spare
 //   noise    8     white_amp, tel_p01, tel_p10, tel_amp, radial zero_radius, ramp_distance,
 //                  full_noise_distance (<=0: none), radial max_amplitude       (a16)
+//   pleads   N     latching: lead acceptance probability per dot                (a14)
+//   pinter   N*N   latching: inter-dot acceptance probabilities                 (a14)
 struct QdLayout {
     int N, G, nb, V;
-    int cdd_inv, cgd, cbg, ufac, uinv, alpha, origin, vopt, vbopt, pmin, pmax, bmin, bmax, scal, noise, size;
+    int cdd_inv, cgd, cbg, ufac, uinv, alpha, origin, vopt, vbopt, pmin, pmax, bmin, bmax, scal, noise, pleads, pinter, size;
     // STATE block (float64, mutable): vgm G*G, gate_v N, barrier_v nb, gate_gt N,
     // barrier_gt nb, sensor_gt 1, kal_mean N*N, kal_var N*N
     int s_vgm, s_gate_v, s_barrier_v, s_gate_gt, s_barrier_gt, s_sensor_gt, s_kmean, s_kvar, s_size;
@@ -62,6 +64,8 @@ QD_HD QdLayout qd_layout(int N) {
     L.bmax = o;    o += L.nb;
     L.scal = o;    o += 4;           // tc_base, gamma, window, spare
     L.noise = o;   o += 8;
+    L.pleads = o;  o += N;
+    L.pinter = o;  o += N * N;
     L.size = (o + 1) & ~1;           // keep blocks 16-byte aligned
     o = 0;
     L.s_vgm = o;        o += L.G * L.G;

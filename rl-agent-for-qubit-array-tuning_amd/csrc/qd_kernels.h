@@ -226,6 +226,65 @@ qd_k_ground(const int* __restrict__ env_ids, int env_base, int R, const double* 
 }
 
 // ---------------------------------------------------------------------------
+// a14: charge latching (ground_state.py:164 -> qarray LatchingModel.add_latching, source absent).
+// UNVERIFIED restatement of its documented behaviour: walk the raster of one channel image in
+// row-major order; the state is reset at the start of each row; a new pixel whose occupations
+// differ (numpy.isclose sense) from the held state in exactly one dot is accepted with
+// probability p_leads[dot], in exactly two dots with p_inter[a][b], otherwise always; a rejected
+// pixel keeps the previous (latched) occupations.  One thread per (env, channel): the walk is
+// serial.  Rewrites occ in place and corrects the sensor constant c0 of latched pixels:
+//   c0 += 2 * sum_i A[N][i] (n_latched_i - n_i).
+// ---------------------------------------------------------------------------
+template <int N>
+__global__ void qd_k_latch(const int* __restrict__ env_ids, int n_env, int R, const double* __restrict__ params,
+                           const double* __restrict__ state, double* __restrict__ occ, double* __restrict__ zraw,
+                           QdNoiseCfg nz) {
+    constexpr int G = N + 1, C = N - 1;
+    const QdLayout L = qd_layout(N);
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_env * C) return;
+    const int slot = t / C, ch = t - slot * C;
+    const int e = env_ids ? env_ids[slot] : slot;
+    const double* par = params + (size_t)e * L.size;
+    const double* st = state + (size_t)e * L.s_size;
+    if (qd_radial_replaced(par, st, L, ch, nz.flags)) return;
+    const int P = R * R;
+    const uint32_t k1 = nz.env_off + (uint32_t)e;
+    double* oc = occ + ((size_t)e * C + ch) * P * N;
+    double* zc = zraw + ((size_t)e * C + ch) * P;
+    double hold[N];
+    for (int p = 0; p < P; ++p) {
+        double nn[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) nn[i] = oc[(size_t)p * N + i];
+        bool accept = true;
+        if (p % R != 0) {
+            int cnt = 0, a = 0, b = 0;
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                const bool differ = !(fabs(hold[i] - nn[i]) <= 1e-8 + 1e-5 * fabs(nn[i]));
+                if (differ) { if (cnt == 0) a = i; else if (cnt == 1) b = i; cnt++; }
+            }
+            if (cnt == 1 || cnt == 2) {
+                const QdPhilox r = qd_philox4x32_10((uint32_t)p, (uint32_t)ch | (QD_RNG_LATCH << 16), nz.ser_lo, nz.ser_hi, nz.seed, k1);
+                const double u = qd_u01(r.v[0], r.v[1]);
+                const double pa = (cnt == 1) ? par[L.pleads + a] : par[L.pinter + a * N + b];
+                accept = u < pa;
+            }
+        }
+        if (accept) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) hold[i] = nn[i];
+        } else {
+            double corr = 0.0;
+#pragma unroll
+            for (int i = 0; i < N; ++i) { corr = fma(par[L.cdd_inv + N * G + i], hold[i] - nn[i], corr); oc[(size_t)p * N + i] = hold[i]; }
+            zc[p] += 2.0 * corr;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // a15 + a16: sensor stage, one pixel per lane, in place on zraw.
 //   in : c0 from qd_k_ground      out: signal = sum_{k=-5..4} 1 / (((c0 + 2 a (k + eta)) / gamma)^2 + 1)
 // eta = sensor-potential noise (white + telegraph), then radial image noise / replacement.

@@ -46,3 +46,4 @@ QD_HD void qd_normal2(const QdPhilox& p, double& z0, double& z1) {
 #define QD_RNG_WHITE 1u
 #define QD_RNG_RADIAL 2u
 #define QD_RNG_TELEGRAPH 3u
+#define QD_RNG_LATCH 4u

@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get("QDSIM_LIB", os.path.join(CSRC, "libqdsim.so"))   # QD
 QD_FLAG_VALIDATE = 1
 QD_NOISE_SENSOR = 1
 QD_NOISE_RADIAL = 2
+QD_NOISE_LATCH = 4
 
 EXPORTS = [
     "qd_param_block_doubles", "qd_state_block_doubles", "qd_layout_query", "qd_create", "qd_destroy",

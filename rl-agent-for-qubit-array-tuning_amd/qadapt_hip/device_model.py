@@ -271,6 +271,9 @@ class DeviceSampler:
         P[:, L.bmin:L.bmin + nb] = bmin; P[:, L.bmax:L.bmax + nb] = bmax
         P[:, L.scal + 0] = a["tc_base"]; P[:, L.scal + 1] = a["coulomb_peak_width"]
         P[:, L.scal + 2] = a["window_delta"]
+        # a14 latching probabilities (qarray_base_class.py:495-519)
+        P[:, L.pleads:L.pleads + N] = a["p_leads"]
+        P[:, L.pinter:L.pinter + N * N] = a["p_inter"].reshape(n, -1)
         # a16 noise parameters (drawn in the reference order above; used only when the handle
         # is created with the corresponding noise flags)
         P[:, L.noise + 0] = a["white_noise_amplitude"]

@@ -25,6 +25,8 @@ class Layout:
     bmax: int
     scal: int
     noise: int
+    pleads: int
+    pinter: int
     size: int
     s_vgm: int
     s_gate_v: int
@@ -43,7 +45,7 @@ def layout(N: int) -> Layout:
     f = {}
     for name, n in (("cdd_inv", G * G), ("cgd", G * V), ("cbg", nb * G), ("ufac", N * N), ("uinv", N),
                     ("alpha", nb), ("origin", G), ("vopt", G), ("vbopt", nb), ("pmin", N),
-                    ("pmax", N), ("bmin", nb), ("bmax", nb), ("scal", 4), ("noise", 8)):
+                    ("pmax", N), ("bmin", nb), ("bmax", nb), ("scal", 4), ("noise", 8), ("pleads", N), ("pinter", N * N)):
         f[name] = o
         o += n
     f["size"] = (o + 1) & ~1
@@ -57,6 +59,6 @@ def layout(N: int) -> Layout:
 
 
 LAYOUT_FIELDS = ["N", "G", "nb", "V", "cdd_inv", "cgd", "cbg", "ufac", "uinv", "alpha", "origin", "vopt",
-                 "vbopt", "pmin", "pmax", "bmin", "bmax", "scal", "noise", "size", "s_vgm", "s_gate_v",
+                 "vbopt", "pmin", "pmax", "bmin", "bmax", "scal", "noise", "pleads", "pinter", "size", "s_vgm", "s_gate_v",
                  "s_barrier_v", "s_gate_gt", "s_barrier_gt", "s_sensor_gt", "s_kmean", "s_kvar",
                  "s_size"]

@@ -115,15 +115,17 @@ class VecQuantumDeviceEnv:
     def _noise_flags(self, noise):
         """noise=None/False: deterministic parity mode.  noise=True: what the configs enable
         (sensor white + telegraph noise always, radial noise if simulator.radial_noise.enabled).
-        Or an iterable of {"sensor", "radial"}."""
+        Or an iterable of {"sensor", "radial", "latch"}."""
         if not noise:
             return 0
         if noise is True:
             rn = self.config["simulator"].get("radial_noise") or {}
-            return _lib.QD_NOISE_SENSOR | (_lib.QD_NOISE_RADIAL if rn.get("enabled") else 0)
+            lt = self.qconfig["simulator"]["model"].get("latching_model_parameters") or {}
+            return (_lib.QD_NOISE_SENSOR | (_lib.QD_NOISE_RADIAL if rn.get("enabled") else 0)
+                    | (_lib.QD_NOISE_LATCH if lt.get("Exists") else 0))
         f = 0
         for k in noise:
-            f |= {"sensor": _lib.QD_NOISE_SENSOR, "radial": _lib.QD_NOISE_RADIAL}[k]
+            f |= {"sensor": _lib.QD_NOISE_SENSOR, "radial": _lib.QD_NOISE_RADIAL, "latch": _lib.QD_NOISE_LATCH}[k]
         return f
 
     def _stream(self):

@@ -82,3 +82,39 @@ def test_noise_changes_between_observations():
     img = obs["image"].cpu().numpy()
     assert np.all((img >= 0) & (img <= 1))
     env.close()
+
+
+def test_latching_identity_when_always_accepted_and_hysteresis_otherwise():
+    """a14 (UNVERIFIED restatement of qarray's LatchingModel): with every acceptance probability
+    equal to 1 latching is the identity; with small probabilities some pixels keep the previous
+    pixel's occupations (hysteresis along the fast scan axis), rows restart clean."""
+    import ctypes
+    from qadapt_hip import _lib
+    offs = [0.5, 1.0, 1.5, 2.0]
+    det = _env(None); z0, _ = _observe_at(det, offs); det.close()
+    env = _env(["latch"])
+    L, N, R = env.L, env.N, env.R
+    # acceptance probabilities all 1 -> identity
+    eb = env.last_episode
+    P1 = eb.params.copy(); P1[:, L.pleads:L.pleads + N] = 1.0; P1[:, L.pinter:L.pinter + N * N] = 1.0
+    ids = np.arange(env.B, dtype=np.int32)
+    st_now, steps_now = env.get_state()                       # keep the VGM / voltages reset() left behind
+    _lib.check(env._h, env._lib.qd_load_episodes(env._h, ids.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), env.B,
+                                                 P1.ctypes.data, st_now.ctypes.data, 0, env._stream()), "load")
+    z1, _ = _observe_at(env, offs)
+    assert np.array_equal(z1, z0)
+    # tiny acceptance probabilities -> held states
+    P2 = eb.params.copy(); P2[:, L.pleads:L.pleads + N] = 0.05; P2[:, L.pinter:L.pinter + N * N] = 0.05
+    _lib.check(env._h, env._lib.qd_load_episodes(env._h, ids.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), env.B,
+                                                 P2.ctypes.data, st_now.ctypes.data, 0, env._stream()), "load")
+    z2, _ = _observe_at(env, offs)
+    occ = env.occupations()
+    changed = z2 != z0
+    assert changed.any()
+    # the first pixel of every row is never latched
+    assert not changed.reshape(env.B, N - 1, R, R)[:, :, :, 0].any()
+    # a latched pixel carries exactly the occupations of its left neighbour
+    idx = np.argwhere(changed)
+    for (e, ch, p) in idx[:50]:
+        assert np.array_equal(occ[e, ch, p], occ[e, ch, p - 1])
+    env.close()

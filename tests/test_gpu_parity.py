@@ -46,7 +46,7 @@ def test_library_exports_and_layout():
         assert hasattr(L, name)
     import ctypes
     for N in range(2, 9):
-        out = (ctypes.c_int32 * 29)()
+        out = (ctypes.c_int32 * 31)()
         assert L.qd_layout_query(N, out) == 0
         py = layout(N)
         assert [getattr(py, f) for f in LAYOUT_FIELDS] == list(out)
