@@ -137,7 +137,7 @@ def main():
         # on the stream the kernels are launched on
         gs_ms = env.time_ground_kernel(iters=2)
         cand_ms = env.time_candidates_kernel(iters=2)
-        chunk = min(B, max(1, (1 << 30) // ((N - 1) * R * R * 216)))
+        chunk = env.chunk_envs()
         alg_bytes = b_alg(N, R) * chunk
         achieved = alg_bytes / (gs_ms * 1e-3) / 1e9
         traffic = None

@@ -142,6 +142,8 @@ int qd_get_candidates(qd_handle* h, int32_t* states_host);
  * kernel (ground state) on the current data and returns the mean duration in
  * milliseconds measured with HIP events on `stream`. */
 int qd_time_ground_kernel(qd_handle* h, int iters, float* mean_ms, void* stream);
+/* Number of env-steps one launch of the hot kernels covers (scratch chunk). */
+int qd_chunk_envs(const qd_handle* h);
 int qd_time_candidates_kernel(qd_handle* h, int iters, float* mean_ms, void* stream);
 
 #ifdef __cplusplus

@@ -384,3 +384,5 @@ extern "C" int qd_time_candidates_kernel(qd_handle* h, int iters, float* mean_ms
     *mean_ms = ms / iters;
     return QD_OK;
 }
+
+extern "C" int qd_chunk_envs(const qd_handle* h) { return h ? h->chunk : -1; }

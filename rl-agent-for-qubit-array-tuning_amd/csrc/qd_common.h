@@ -87,6 +87,7 @@ QD_HD QdLayout qd_layout(int N) {
 //   int32  nvalid    number of valid candidates (<32 => rest are |0..0> padding)
 //   double vpp[9]    cgd_full @ v_ext  (first N entries = v')
 //   double tc[7]     tunnel couplings of the N-1 adjacent pairs
+//   double E[32]     canonical energies of the kept candidates (= the diagonal F of H)
 struct __attribute__((aligned(8))) QdPixelRec {
     uint16_t idx[QD_K];
     int32_t fl[QD_MAXN];
@@ -94,4 +95,5 @@ struct __attribute__((aligned(8))) QdPixelRec {
     int32_t pad;
     double vpp[QD_MAXN + 1];
     double tc[QD_MAXN - 1];
+    double E[QD_K];
 };

@@ -155,25 +155,29 @@ __device__ void qd_ground_pixel(const double* __restrict__ A, const QdPixelRec* 
     const unsigned code = valid ? (unsigned)rec->idx[m] : 0u;
     int n[N];
     unsigned ecode = 0;
-    double F = 0.0;
-    {
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const int dig = (code >> (2 * (N - 1 - i))) & 3;
+        n[i] = valid ? W.pfl[hh][i] + dig - 1 : 0;
+        ecode |= (unsigned)dig << (4 * (N - 1 - i));
+    }
+    // F_m: the candidate kernel already evaluated the canonical energy of every kept state; only
+    // the |0..0> padding (fewer than 32 valid candidates: N <= 3) is evaluated here
+    double F = valid ? rec->E[m] : 0.0;
+    if (nvalid < QD_K) {
         double dd[N];
 #pragma unroll
-        for (int i = 0; i < N; ++i) {
-            const int dig = (code >> (2 * (N - 1 - i))) & 3;
-            n[i] = valid ? W.pfl[hh][i] + dig - 1 : 0;
-            dd[i] = (double)n[i] - pvv[i];
-            ecode |= (unsigned)dig << (4 * (N - 1 - i));
-        }
-        // rolled over rows: a fully unrolled N x N form keeps all of A in registers
+        for (int i = 0; i < N; ++i) dd[i] = 0.0 - pvv[i];
+        double F0 = 0.0;
 #pragma unroll 1
         for (int i = 0; i < N; ++i) {
             double t = qd_dotN<N>(A + i * G, dd);
             double di = dd[0];
 #pragma unroll
             for (int j = 1; j < N; ++j) di = (j == i) ? dd[j] : di;
-            F = fma(di, t, F);
+            F0 = fma(di, t, F0);
         }
+        if (!valid) F = F0;
     }
 
     // ---- 2. hop neighbours -------------------------------------------------
@@ -221,7 +225,9 @@ __device__ void qd_ground_pixel(const double* __restrict__ A, const QdPixelRec* 
                 // Y < 0: s_j = s_i - e_d + e_{d+1} (forward); else backward
                 const double prod = (Y < 0) ? (double)nd * ((double)nd1 + 1.0)
                                             : (double)nd1 * ((double)nd + 1.0);
-                c = -t * sqrt(prod);
+                double sq_ = 0.0, rs_ = 0.0;
+                if (prod > 0.0) qd_sqrt_rsqrt(prod, sq_, rs_);
+                c = -t * sq_;
             }
 #pragma unroll
             for (int i = 0; i < QD_NBREG; ++i) if (i == s) { nbc[i] = c; nbi[i] = j; }

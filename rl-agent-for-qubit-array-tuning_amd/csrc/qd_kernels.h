@@ -158,6 +158,8 @@ qd_k_candidates(const int* __restrict__ env_ids, int env_base, int R, const doub
 #pragma unroll
     for (int m = 0; m < QD_K; ++m) rec->idx[m] = m < nv ? sid[m * QD_CAND_BLOCK + threadIdx.x] : 0;
 #pragma unroll
+    for (int m = 0; m < QD_K; ++m) rec->E[m] = se[m * QD_CAND_BLOCK + threadIdx.x];   // only m < nvalid is read
+#pragma unroll
     for (int i = 0; i < N; ++i) rec->fl[i] = fl[i];
     rec->nvalid = nv;
 #pragma unroll

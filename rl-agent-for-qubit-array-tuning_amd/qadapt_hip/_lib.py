@@ -19,7 +19,7 @@ EXPORTS = [
     "qd_param_block_doubles", "qd_state_block_doubles", "qd_layout_query", "qd_create", "qd_destroy",
     "qd_last_error", "qd_bind_outputs", "qd_load_episodes", "qd_apply_actions", "qd_observe",
     "qd_update_capacitance", "qd_step", "qd_get_state", "qd_set_state", "qd_get_raw",
-    "qd_get_occupations", "qd_get_candidates", "qd_time_ground_kernel", "qd_time_candidates_kernel",
+    "qd_get_occupations", "qd_get_candidates", "qd_time_ground_kernel", "qd_time_candidates_kernel", "qd_chunk_envs",
 ]
 
 
@@ -92,6 +92,7 @@ def lib():
     L.qd_time_ground_kernel.restype = ctypes.c_int
     L.qd_time_candidates_kernel.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_float), vp]
     L.qd_time_candidates_kernel.restype = ctypes.c_int
+    L.qd_chunk_envs.argtypes = [vp]; L.qd_chunk_envs.restype = ctypes.c_int
     _LIB = L
     return L
 

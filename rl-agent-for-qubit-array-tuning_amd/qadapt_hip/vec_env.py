@@ -305,3 +305,7 @@ class VecQuantumDeviceEnv:
         _lib.check(self._h, self._lib.qd_time_candidates_kernel(self._h, iters, ctypes.byref(ms), self._stream()),
                    "qd_time_candidates_kernel")
         return float(ms.value)
+
+    def chunk_envs(self):
+        """env-steps covered by one launch of the hot kernels."""
+        return int(self._lib.qd_chunk_envs(self._h))
