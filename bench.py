@@ -40,6 +40,13 @@ def b_alg(N, R):
     return 8 * n_par + 4 * (N - 1) * R * R + 4 * (3 * N - 1) * R * R
 
 
+def f_alg(N, R):
+    """literal-reference flops per env-step."""
+    K, G = 32, N + 1
+    per_pixel = 4 ** N * (2 * N * N + 3 * N) + K * (2 * N * N + 3 * N) + 9 * K ** 3 + 22 * G * G
+    return per_pixel * (N - 1) * R * R
+
+
 def cpu_baseline(N, R, seconds_budget=20.0):
     """The plain-C oracle (literal reference algorithm, OpenMP) on the host cores,
     on a bounded sample: whole channels of one env until the budget is used."""
@@ -162,6 +169,14 @@ def main():
                          "second_kernel": f"qd_k_candidates<{N}>", "second_kernel_ms": cand_ms,
                          "note": "the faithful path is float64 VALU/LDS bound, not HBM bound (SURVEY 7-H1); "
                                  "the HBM fraction is reported as the contract asks, see DESIGN.md"},
+            # SURVEY 8(d) asks for both rooflines.  F_alg is the LITERAL reference flop count per env-step
+            # (4^N-candidate scan + dense 32x32 eigh per pixel); the kernels do far less work than that
+            # (exact k-best search, block-wise Lanczos), so the "literal-equivalent" rate may exceed the
+            # float64 vector peak -- it measures algorithmic savings, not pipeline utilisation (measured
+            # VALU utilisation of the ground kernel is ~50 %, profiles/r01_b_pmc_summary.csv).
+            "valu": {"literal_flops_per_env_step": f_alg(N, R),
+                     "literal_equivalent_tflops": f_alg(N, R) * value / world / 1e12,
+                     "fp64_vector_peak_tflops": FP64_VECTOR_PEAK_TFLOPS},
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(N, R, args.cpu_seconds)
