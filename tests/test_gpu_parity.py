@@ -53,7 +53,7 @@ def test_library_exports_and_layout():
 
 
 @pytest.mark.parametrize("N,R,mode", [(2, 32, "near"), (2, 16, "far"), (3, 16, "mid"), (4, 32, "near"),
-                                       (4, 16, "mid"), (6, 12, "near"), (8, 16, "near"), (8, 8, "mid")])
+                                       (4, 16, "mid"), (5, 12, "mid"), (6, 12, "near"), (7, 8, "near"), (8, 16, "near"), (8, 8, "mid")])
 def test_csd_pipeline_matches_oracle(N, R, mode):
     B = 3
     env = _env(B, N, R)
