@@ -2,7 +2,7 @@
 // code: sweep-voltage synthesis (a5), continuous ground state (a8), EXACT
 // k-best candidate search (a9), barrier couplings (a10), sensor stage (a15).
 // The same source is compiled into the HIP kernels and into the CPU-only test
-// harness (qd_hosttest.cpp) so its integer results can be checked against the
+// harness (tests/hosttest/qd_hosttest.cpp) so its integer results can be checked against the
 // oracle without a GPU.
 //
 // Reference rows (file:line under /root/reference):

@@ -79,8 +79,9 @@ _HOST = None
 def hosttest():
     global _HOST
     if _HOST is None:
-        subprocess.check_call(["make", "-s", "-C", CSRC, "hosttest"])
-        _HOST = ctypes.CDLL(os.path.join(CSRC, "libqdsim_hosttest.so"))
+        hdir = os.path.join(ROOT, "tests", "hosttest")
+        subprocess.check_call(["make", "-s", "-C", hdir, "libqdsim_hosttest.so"])
+        _HOST = ctypes.CDLL(os.path.join(hdir, "libqdsim_hosttest.so"))
         _HOST.qdh_sensor.restype = ctypes.c_double
     return _HOST
 

@@ -3,7 +3,7 @@
 // state, exact k-best search, sensor stage) can be checked against the oracle
 // in the no-GPU test tier.  It is NOT part of the product: nothing in
 // qadapt_hip loads it, and it contains no ground-state solver (that stage only
-// exists as HIP code).  Built by tests via csrc/Makefile target hosttest.
+// exists as HIP code).  Built by tests/hosttest/Makefile.
 #include <string.h>
 #include "qd_pixel.h"
 #include "qd_rng.h"
