@@ -178,7 +178,7 @@ def main():
                      "literal_equivalent_tflops": f_alg(N, R) * value / world / 1e12,
                      "fp64_vector_peak_tflops": FP64_VECTOR_PEAK_TFLOPS},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:          # reported at N = 1 only
             out["cpu_baseline"] = cpu_baseline(N, R, args.cpu_seconds)
         print(json.dumps(out))
     env.close()
