@@ -481,3 +481,29 @@ def test_dataset_generator_format_and_values(tmp_path):
     ok = np.abs(images[0] - ref) <= 1e-5 * (1 + np.abs(ref))
     assert ok.mean() > 0.99
     gen.close()
+
+
+def test_nan_inputs_give_zero_image_not_a_hang():
+    """env.py:499-506: if the percentiles are not ordered (NaN data) the normalised image is all
+    zeros.  A poisoned parameter block must neither hang nor fault the kernels, and must not
+    affect the other envs of the batch."""
+    import ctypes
+    from qadapt_hip import _lib
+    N, R, B = 4, 8, 2
+    env = _env(B, N, R)
+    env.reset()
+    good = env.global_image.cpu().numpy().copy()
+    eb = env.last_episode
+    L = env.L
+    P = eb.params.copy()
+    P[1, L.cgd + 3] = np.nan
+    st, steps = env.get_state()
+    ids = np.arange(B, dtype=np.int32)
+    _lib.check(env._h, env._lib.qd_load_episodes(env._h, ids.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), B,
+                                                 P.ctypes.data, st.ctypes.data, 0, env._stream()), "load")
+    _lib.check(env._h, env._lib.qd_observe(env._h, None, 0, env._stream()), "observe")
+    img = env.global_image.cpu().numpy()
+    raw, plohi = env.raw()
+    assert np.isnan(plohi[1]).all() and np.all(img[1] == 0)
+    assert np.isfinite(raw[0]).all() and np.isfinite(img[0]).all() and img[0].max() == 1.0
+    env.close()
