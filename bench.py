@@ -93,6 +93,10 @@ def main():
                     help="torch.distributed backend for the barrier / max-time reduction (gloo: rehearsal of N>1 on one GPU)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: all ranks use cuda:0")
     ap.add_argument("--noise", action="store_true", help="all stochastic stages on (throughput only)")
+    ap.add_argument("--cnn", default="synthetic", choices=["synthetic", "mobilenet", "impala"],
+                    help="capacitance model inside the step: synthetic outputs (the metric's definition, SURVEY 8d) or the "
+                         "reference's CNN architecture with random weights running on the device (row f1)")
+    ap.add_argument("--cnn-dtype", default="float32", choices=["float32", "bfloat16"])
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -111,8 +115,13 @@ def main():
     dev = torch.device(f"cuda:{local}")
     from qadapt_hip import shard as _shard
     first_env, _ = _shard.shard_env_ids(rank, world, B)
+    if args.cnn == "synthetic":
+        cap_model = SyntheticCapacitanceModel(99 + rank)
+    else:
+        from qadapt_hip.capacitance_cnn import build_device_model
+        cap_model = build_device_model(backbone=args.cnn, device=dev, seed=7, dtype=getattr(torch, args.cnn_dtype))
     env = VecQuantumDeviceEnv(B, num_dots=N, resolution=R, device=dev, seed=1234, env_id_offset=first_env,
-                              capacitance_model=SyntheticCapacitanceModel(99 + rank), noise=True if args.noise else None)
+                              capacitance_model=cap_model, noise=True if args.noise else None)
     gen = torch.Generator(device="cpu").manual_seed(99 + rank)
     env.reset()
 
@@ -160,7 +169,9 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{N}-dot array, {B} parallel envs per GPU, {R}x{R} CSD, "
                                    + ("all stochastic stages on" if args.noise else "deterministic physics (latching/noise off)")
-                                   + ", 50-step episodes with auto-reset, synthetic CNN outputs",
+                                   + ", 50-step episodes with auto-reset, "
+                                   + ("synthetic CNN outputs" if args.cnn == "synthetic" else
+                                      f"{args.cnn} capacitance CNN ({args.cnn_dtype}, random weights) on the device inside the step"),
                        "n_dots": N, "envs_per_gpu": B, "resolution": R, "pixels_per_s": value * (N - 1) * R * R},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

@@ -57,9 +57,11 @@ class QuantumDeviceEnv:
                 if not capacitance_model_checkpoint:
                     raise ValueError("Capacitance model weights must be provided via capacitance_model_checkpoint "
                                      f"when using update_method '{update_method}'.")
-                raise FileNotFoundError(
-                    f"capacitance CNN checkpoints ({capacitance_model_checkpoint}) are not loadable here "
-                    "(SURVEY row f1: the CNN is an input provider); pass capacitance_model=callable")
+                # env.py:716-749: CapacitancePredictionModel(output_size) + checkpoint, on the GPU
+                from .capacitance_cnn import build_device_model
+                nearest = self.config["capacitance_model"].get("nearest_neighbour", False)
+                capacitance_model = build_device_model(checkpoint=capacitance_model_checkpoint,
+                                                       output_size=2 if nearest else 3)
         except Exception as e:
             raise RuntimeError(f"Error initialising capacitance model: {e}")
         if backend is None:
