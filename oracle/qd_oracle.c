@@ -76,12 +76,29 @@ static void qd_pixel_voltages(int N, const double *vgm, const double *origin,
     for (int i = 0; i < G; ++i) vg[i] = qd_dot(vgm + (size_t)i * G, Vd, G) + origin[i];
 }
 
+/* ---- f4: linear voltage-dependent capacitances (voltage_dependent_capacitance.py:72-88,
+ *      ground_state.py:53-57): cdd(V) = cdd_full*sa, cgd(V) = cgd_full*sb with
+ *      sa = 1 + alpha*mean|v_ext|, sb = 1 + beta*mean|v_ext|, used by the ground-state stage only.
+ *      Canonical form (shared with csrc/qd_pixel.h): v' scaled by sb, gradient step 0.1/sa,
+ *      energies of the constant-A metric multiplied by 1/sa.  vc == NULL: sa = sb = 1 (exact). */
+static void qd_cap_scales(int V, const double *v_ext, const double *vc, double *sa, double *sb) {
+    *sa = 1.0; *sb = 1.0;
+    if (vc) {
+        double sum = 0.0;
+        for (int j = 0; j < V; ++j) sum += fabs(v_ext[j]);
+        double mabs = sum / (double)V;
+        *sa = fma(vc[0], mabs, 1.0);
+        *sb = fma(vc[1], mabs, 1.0);
+    }
+}
+
 /* ---- a8: continuous ground state (charge_states.py:36-88) ---------------- */
 static void qd_continuous(int N, int G, int V, const double *cdd_inv, const double *cgd,
-                          const double *v_ext, double *vdash, double *n_cont) {
+                          const double *v_ext, double sa, double sb, double *vdash, double *n_cont) {
     int all_pos = 1;
+    const double lr = 0.1 / sa;
     for (int i = 0; i < N; ++i) {
-        vdash[i] = qd_dot(cgd + (size_t)i * V, v_ext, V);
+        vdash[i] = qd_dot(cgd + (size_t)i * V, v_ext, V) * sb;
         n_cont[i] = vdash[i];
         if (!(vdash[i] >= 0.0)) all_pos = 0;
     }
@@ -93,7 +110,7 @@ static void qd_continuous(int N, int G, int V, const double *cdd_inv, const doub
             for (int i = 0; i < N; ++i) {
                 double g1 = qd_dot(cdd_inv + (size_t)i * G, n, N);
                 double grad = g1 - g2[i];
-                double v = n[i] - 0.1 * grad;
+                double v = n[i] - lr * grad;
                 nn[i] = v > 0.0 ? v : 0.0;
             }
             memcpy(n, nn, sizeof(double) * N);
@@ -179,14 +196,14 @@ static void qd_jacobi_ground(double *A /*n*n, destroyed*/, int n, double *vec, d
 }
 
 /* ---- a11-a13: H = diag(F) + H_t, ground state, <n> ------------------------ */
-static void qd_ground_occupation(int N, int G, const double *cdd_inv, const double *vdash,
+static void qd_ground_occupation(int N, int G, const double *cdd_inv, const double *vdash, double isa,
                                  const int32_t *states, const double *tc, double *occ, double *lam_out) {
     double H[QD_K * QD_K];
     double d[QD_MAXN];
     memset(H, 0, sizeof(H));
     for (int m = 0; m < QD_K; ++m) {
         for (int i = 0; i < N; ++i) d[i] = (double)states[m * N + i] - vdash[i];
-        H[m * QD_K + m] = qd_energy(cdd_inv, G, d, N);
+        H[m * QD_K + m] = qd_energy(cdd_inv, G, d, N) * isa;
     }
     for (int i = 0; i < QD_K; ++i)
         for (int j = 0; j < QD_K; ++j) {
@@ -235,12 +252,12 @@ static double qd_sensor(int N, int G, int V, const double *cdd_inv, const double
 /* One CSD channel of one env.  All matrices row-major float64.
  *   cdd_inv G*G, cgd G*V, Cbg nb*G, alpha nb, vgm G*G, origin G, gate_v N, barrier_v nb
  * Outputs (any may be NULL): states P*32*N, floors P*N, occ P*N, z P, tc_out P*nb. */
-int qdo_csd_channel(int N, int R, const double *cdd_inv, const double *cgd, const double *Cbg,
-                    const double *alpha, double tc_base, double gamma,
-                    const double *vgm, const double *origin, const double *gate_v, double sensor_v,
-                    const double *barrier_v, double window, int ch,
-                    int32_t *states_out, int32_t *floors_out, double *occ_out, double *z_out,
-                    double *tc_out, int pix_begin, int pix_end) {
+int qdo_csd_channel_vc(int N, int R, const double *cdd_inv, const double *cgd, const double *Cbg,
+                       const double *alpha, double tc_base, double gamma,
+                       const double *vgm, const double *origin, const double *gate_v, double sensor_v,
+                       const double *barrier_v, double window, int ch,
+                       int32_t *states_out, int32_t *floors_out, double *occ_out, double *z_out,
+                       double *tc_out, int pix_begin, int pix_end, const double *vc /* NULL or {alpha, beta} */) {
     if (N < 2 || N > QD_MAXN || ch < 0 || ch >= N - 1 || R < 1) return 1;
     int G = N + 1, nb = N - 1, V = G + nb;
     if (pix_end < 0) pix_end = R * R;
@@ -251,13 +268,15 @@ int qdo_csd_channel(int N, int R, const double *cdd_inv, const double *cgd, cons
         int32_t st[QD_K * QD_MAXN];
         qd_pixel_voltages(N, vgm, origin, gate_v, sensor_v, window, ch, R, x, y, v_ext);
         for (int b = 0; b < nb; ++b) v_ext[G + b] = barrier_v[b];
-        qd_continuous(N, G, V, cdd_inv, cgd, v_ext, vdash, n_cont);
+        double sa, sb;
+        qd_cap_scales(V, v_ext, vc, &sa, &sb);
+        qd_continuous(N, G, V, cdd_inv, cgd, v_ext, sa, sb, vdash, n_cont);
         qd_candidates(N, G, cdd_inv, vdash, n_cont, st, floors_out ? floors_out + (size_t)p * N : NULL);
         for (int b = 0; b < nb; ++b) {
             double vb_eff = barrier_v[b] + qd_dot(Cbg + (size_t)b * G, v_ext, G);
             tc[b] = tc_base * exp(-alpha[b] * vb_eff);
         }
-        qd_ground_occupation(N, G, cdd_inv, vdash, st, tc, occ, NULL);
+        qd_ground_occupation(N, G, cdd_inv, vdash, 1.0 / sa, st, tc, occ, NULL);
         double z = qd_sensor(N, G, V, cdd_inv, cgd, v_ext, occ, gamma);
         if (states_out) memcpy(states_out + (size_t)p * QD_K * N, st, sizeof(int32_t) * QD_K * N);
         if (occ_out) memcpy(occ_out + (size_t)p * N, occ, sizeof(double) * N);
@@ -265,6 +284,17 @@ int qdo_csd_channel(int N, int R, const double *cdd_inv, const double *cgd, cons
         if (z_out) z_out[p] = z;
     }
     return 0;
+}
+
+int qdo_csd_channel(int N, int R, const double *cdd_inv, const double *cgd, const double *Cbg,
+                    const double *alpha, double tc_base, double gamma,
+                    const double *vgm, const double *origin, const double *gate_v, double sensor_v,
+                    const double *barrier_v, double window, int ch,
+                    int32_t *states_out, int32_t *floors_out, double *occ_out, double *z_out,
+                    double *tc_out, int pix_begin, int pix_end) {
+    return qdo_csd_channel_vc(N, R, cdd_inv, cgd, Cbg, alpha, tc_base, gamma, vgm, origin, gate_v, sensor_v,
+                              barrier_v, window, ch, states_out, floors_out, occ_out, z_out, tc_out,
+                              pix_begin, pix_end, NULL);
 }
 
 /* ---- a17: percentile normalisation, numpy 'linear' method ---------------- */
@@ -307,17 +337,27 @@ int qdo_normalise(const double *z, long n, float *out, double *plo_hi) {
     return 0;
 }
 
-/* whole raw observation of one env: z_out laid out [C][R*R] */
+/* whole raw observation of one env: z_out laid out [C][R*R].
+ * gammas: NULL (constant peak width `gamma`) or one width per channel (f4 variable peak width) */
+int qdo_env_images_vc(int N, int R, const double *cdd_inv, const double *cgd, const double *Cbg,
+                      const double *alpha, double tc_base, double gamma, const double *vgm,
+                      const double *origin, const double *gate_v, double sensor_v,
+                      const double *barrier_v, double window, double *z_out, double *occ_out,
+                      const double *vc, const double *gammas) {
+    for (int ch = 0; ch < N - 1; ++ch) {
+        int rc = qdo_csd_channel_vc(N, R, cdd_inv, cgd, Cbg, alpha, tc_base, gammas ? gammas[ch] : gamma, vgm, origin,
+                                    gate_v, sensor_v, barrier_v, window, ch, NULL, NULL,
+                                    occ_out ? occ_out + (size_t)ch * R * R * N : NULL,
+                                    z_out + (size_t)ch * R * R, NULL, 0, -1, vc);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
 int qdo_env_images(int N, int R, const double *cdd_inv, const double *cgd, const double *Cbg,
                    const double *alpha, double tc_base, double gamma, const double *vgm,
                    const double *origin, const double *gate_v, double sensor_v,
                    const double *barrier_v, double window, double *z_out, double *occ_out) {
-    for (int ch = 0; ch < N - 1; ++ch) {
-        int rc = qdo_csd_channel(N, R, cdd_inv, cgd, Cbg, alpha, tc_base, gamma, vgm, origin, gate_v,
-                                 sensor_v, barrier_v, window, ch, NULL, NULL,
-                                 occ_out ? occ_out + (size_t)ch * R * R * N : NULL,
-                                 z_out + (size_t)ch * R * R, NULL, 0, -1);
-        if (rc) return rc;
-    }
-    return 0;
+    return qdo_env_images_vc(N, R, cdd_inv, cgd, Cbg, alpha, tc_base, gamma, vgm, origin, gate_v, sensor_v,
+                             barrier_v, window, z_out, occ_out, NULL, NULL);
 }

@@ -81,7 +81,7 @@ class Device:
 
     def __init__(self, Cdd, Cgd, Cds, Cgs, Cbd, Cbg, Cbs, Cbb, tc_base, alpha,
                  coulomb_peak_width, optimal_tc=1e-3,
-                 optimal_center=(1.0, 0.53)):
+                 optimal_center=(1.0, 0.53), vc=None, vpw_alpha=None):
         self.Cdd = np.asarray(Cdd, float); self.Cgd = np.asarray(Cgd, float)
         self.Cds = np.asarray(Cds, float).reshape(1, -1)
         self.Cgs = np.asarray(Cgs, float).reshape(1, -1)
@@ -95,6 +95,11 @@ class Device:
         self.alpha = np.asarray(alpha, float).reshape(-1)
         self.gamma = float(coulomb_peak_width)
         self.optimal_tc = float(optimal_tc)
+        # f4 options (off in the reference's default configuration):
+        #   vc = (alpha, beta): linear voltage-dependent capacitances (qarray_base_class.py:840-852)
+        #   vpw_alpha: variable peak width (qarray_base_class.py:856-863)
+        self.vc = None if vc is None else (float(vc[0]), float(vc[1]))
+        self.vpw_alpha = None if vpw_alpha is None else float(vpw_alpha)
         self.cdd_full, self.cdd_inv_full, self.cgd_full = \
             maxwell_with_barriers_and_sensor(self.Cdd, self.Cgd, self.Cds,
                                              self.Cgs, self.Cbd, self.Cbs)
@@ -288,10 +293,24 @@ def ground_state_open(dev: Device, vg, vb, return_states=False, fast_candidates=
     v_ext = np.concatenate([vg, vb], axis=-1)
     N = dev.n_dot
     fn = candidate_states if fast_candidates else candidate_states_literal
-    states, _ = fn(v_ext, dev.cdd_inv_full, dev.cgd_full, N)
     vb_eff = effective_barrier_potential(vg, vb, dev.Cbg, dev.Cbb)
     tc = tunnel_couplings(vb_eff, dev.tc_base, dev.alpha)
-    F = free_energy_states(v_ext, dev.cdd_inv_full, dev.cgd_full, states, N)
+    if getattr(dev, "vc", None) is None:
+        states, _ = fn(v_ext, dev.cdd_inv_full, dev.cgd_full, N)
+        F = free_energy_states(v_ext, dev.cdd_inv_full, dev.cgd_full, states, N)
+    else:
+        # ground_state.py:53-57 with create_linear_capacitance_model (voltage_dependent_capacitance.py:72-88,
+        # 125-137): per-pixel matrices cdd_0*(1+alpha*mean|v|), inv of that, cgd_0*(1+beta*mean|v|).
+        # Literal and slow (one pixel at a time); small cases only.
+        a_, b_ = dev.vc
+        st_l, F_l = [], []
+        for p in range(v_ext.shape[0]):
+            m = np.mean(np.abs(v_ext[p]))
+            cdd_inv_p = np.linalg.inv(dev.cdd_full * (1 + a_ * m))
+            cgd_p = dev.cgd_full * (1 + b_ * m)
+            s_p, _ = fn(v_ext[p:p + 1], cdd_inv_p, cgd_p, N)
+            st_l.append(s_p); F_l.append(free_energy_states(v_ext[p:p + 1], cdd_inv_p, cgd_p, s_p, N))
+        states = np.concatenate(st_l); F = np.concatenate(F_l)
     M = states.shape[1]
     H = F[:, :, None] * np.eye(M) + tunnel_hamiltonian(tc, states)
     _, vecs = np.linalg.eigh(H)
@@ -307,7 +326,7 @@ def ground_state_open(dev: Device, vg, vb, return_states=False, fast_candidates=
 # a15  charge-sensor response  (TunnelCoupledChargeSensed.py:320-380,
 #      lorentzian _helper_functions.py:167-177); noise model = none
 # --------------------------------------------------------------------------
-def charge_sensor_open(dev: Device, vg, vb, n_open=None):
+def charge_sensor_open(dev: Device, vg, vb, n_open=None, gamma=None):
     vg = np.asarray(vg, float).reshape(-1, dev.n_gate)
     vb = np.asarray(vb, float).reshape(-1, dev.n_barrier)
     if n_open is None:
@@ -326,7 +345,7 @@ def charge_sensor_open(dev: Device, vg, vb, n_open=None):
         F[i, ..., 0] = np.einsum('...i,ij,...j', d, dev.cdd_inv_full, d)
     with np.errstate(divide='ignore', invalid='ignore'):
         x = np.diff(F, axis=0)
-        signal = np.reciprocal((x / dev.gamma) ** 2 + 1).sum(axis=0)
+        signal = np.reciprocal((x / (dev.gamma if gamma is None else gamma)) ** 2 + 1).sum(axis=0)
     return signal, n_open
 
 
@@ -342,7 +361,12 @@ def get_obs_images(dev: Device, vgm, origin, gate_voltages, barrier_voltages,
         vg = sweep_voltages(vgm, origin, gate_voltages, sensor_voltage, ch,
                             -window, window, R)
         vb = np.broadcast_to(np.asarray(barrier_voltages, float), (vg.shape[0], N - 1))
-        z, n_open = charge_sensor_open(dev, vg, vb)
+        gamma = None
+        if getattr(dev, "vpw_alpha", None) is not None:
+            # qarray_base_class.py:192-196 + utils/vary_peak_width.py:8-12 (virtual plunger voltages)
+            v_avg = (abs(gate_voltages[ch]) + abs(gate_voltages[ch + 1])) / 2
+            gamma = np.clip(dev.gamma - np.abs(dev.vpw_alpha * v_avg), 0, 1)
+        z, n_open = charge_sensor_open(dev, vg, vb, gamma=gamma)
         imgs.append(z.reshape(R, R)); occs.append(n_open.reshape(R, R, N))
     img = np.stack(imgs, axis=-1)
     if return_occupations:

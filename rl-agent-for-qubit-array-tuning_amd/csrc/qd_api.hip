@@ -229,7 +229,7 @@ extern "C" int qd_observe(qd_handle* h, const int32_t* env_ids, int n, void* str
     if (n == 0) return QD_OK;
     if (n > h->B) return qd_fail(h, QD_ERR_ARG, "qd_observe: n > batch");
     const QdLayout& L = h->L;
-    const size_t shm = sizeof(double) * (L.size + L.s_size) + (size_t)QD_K * QD_CAND_BLOCK * (sizeof(double) + sizeof(uint16_t));
+    const size_t shm = (size_t)QD_K * QD_CAND_BLOCK * (sizeof(double) + sizeof(uint16_t));
     h->obs_serial++;
     if (h->cfg.noise_flags & QD_NOISE_SENSOR) {
         const int nt = n * h->C;
@@ -368,8 +368,7 @@ extern "C" int qd_time_candidates_kernel(qd_handle* h, int iters, float* mean_ms
     hipEvent_t a, b;
     QD_HIP(hipEventCreate(&a)); QD_HIP(hipEventCreate(&b));
     const int cnt = h->chunk < h->B ? h->chunk : h->B;
-    const QdLayout& L = h->L;
-    const size_t shm = sizeof(double) * (L.size + L.s_size) + (size_t)QD_K * QD_CAND_BLOCK * (sizeof(double) + sizeof(uint16_t));
+    const size_t shm = (size_t)QD_K * QD_CAND_BLOCK * (sizeof(double) + sizeof(uint16_t));
     dim3 g1(qd_cand_blocks(h->R), h->C, cnt);
     QD_HIP(hipEventRecord(a, s));
     for (int i = 0; i < iters; ++i) {

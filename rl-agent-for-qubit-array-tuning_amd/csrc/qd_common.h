@@ -32,7 +32,8 @@
 //   vopt     G     optimal physical gate voltages             (a21)
 //   vbopt    nb    barrier ground truth                       (a21)
 //   pmin,pmax N ; bmin,bmax nb   action ranges                (a2)
-//   tc_base, gamma, window, spare
+//   scal     8     tc_base, gamma (coulomb_peak_width), window, vpw_alpha (<0: constant peak width),
+//                  vc_on (0/1), vc_alpha, vc_beta (linear voltage-dependent capacitances), spare   (f4)
 //   noise    8     white_amp, tel_p01, tel_p10, tel_amp, radial zero_radius, ramp_distance,
 //                  full_noise_distance (<=0: none), radial max_amplitude       (a16)
 //   pleads   N     latching: lead acceptance probability per dot                (a14)
@@ -62,7 +63,7 @@ QD_HD QdLayout qd_layout(int N) {
     L.pmax = o;    o += N;
     L.bmin = o;    o += L.nb;
     L.bmax = o;    o += L.nb;
-    L.scal = o;    o += 4;           // tc_base, gamma, window, spare
+    L.scal = o;    o += 8;           // tc_base, gamma, window, vpw_alpha, vc_on, vc_alpha, vc_beta, spare
     L.noise = o;   o += 8;
     L.pleads = o;  o += N;
     L.pinter = o;  o += N * N;

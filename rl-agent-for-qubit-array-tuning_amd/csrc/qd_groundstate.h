@@ -133,9 +133,7 @@ __device__ __forceinline__ double qd_seg_max(double v, const QdMembers& M, int s
 // lanes (LDS).  rec: this half's pixel record.  On return every lane of the half
 // holds the expectation occupations occ[0..N) and the ground energy.
 template <int N>
-__device__ void qd_ground_pixel(const double* __restrict__ A, const QdPixelRec* __restrict__ rec,
-                                QdWaveLds& W, double* occ, double* lam_out) {
-    constexpr int G = N + 1;
+__device__ void qd_ground_pixel(const QdPixelRec* __restrict__ rec, QdWaveLds& W, double* occ, double* lam_out) {
     const int lane = threadIdx.x & 63;
     const int m = lane & 31;
     const int hb = lane & 32;
@@ -161,24 +159,9 @@ __device__ void qd_ground_pixel(const double* __restrict__ A, const QdPixelRec* 
         n[i] = valid ? W.pfl[hh][i] + dig - 1 : 0;
         ecode |= (unsigned)dig << (4 * (N - 1 - i));
     }
-    // F_m: the candidate kernel already evaluated the canonical energy of every kept state; only
-    // the |0..0> padding (fewer than 32 valid candidates: N <= 3) is evaluated here
-    double F = valid ? rec->E[m] : 0.0;
-    if (nvalid < QD_K) {
-        double dd[N];
-#pragma unroll
-        for (int i = 0; i < N; ++i) dd[i] = 0.0 - pvv[i];
-        double F0 = 0.0;
-#pragma unroll 1
-        for (int i = 0; i < N; ++i) {
-            double t = qd_dotN<N>(A + i * G, dd);
-            double di = dd[0];
-#pragma unroll
-            for (int j = 1; j < N; ++j) di = (j == i) ? dd[j] : di;
-            F0 = fma(di, t, F0);
-        }
-        if (!valid) F = F0;
-    }
+    // F_m: the candidate kernel already evaluated the canonical energy of every kept state, and of the
+    // |0..0> padding when fewer than 32 candidates are valid (N <= 3)
+    const double F = rec->E[m];
 
     // ---- 2. hop neighbours -------------------------------------------------
     // pairs whose coupling is exactly zero do not link states (keeps the classical

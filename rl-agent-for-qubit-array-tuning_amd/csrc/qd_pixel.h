@@ -42,14 +42,14 @@ QD_HD double qd_linspace(double start, double stop, int R, int i) {
 }
 
 // ---------------------------------------------------------------------------
-// a5 + a8 + a10 front end of one pixel.
+// a5 + a10 front end of one pixel: voltages and tunnel couplings.
 //   par: env parameter block, st: env state block (layout qd_layout(N)).
 // Outputs: v_ext[V] = [physical gate voltages (G), barrier voltages (nb)],
-//          vpp[G] = cgd_full @ v_ext (vpp[0..N) is v'), ncont[N], tc[nb].
+//          vpp[G] = cgd_full @ v_ext (constant matrices: what the sensor stage uses), tc[nb].
 // ---------------------------------------------------------------------------
 template <int N>
-QD_HD void qd_pixel_front(const double* par, const double* st, int ch, int R, int x, int y,
-                          double* v_ext, double* vpp, double* ncont, double* tc) {
+QD_HD void qd_pixel_voltages(const double* par, const double* st, int ch, int R, int x, int y,
+                             double* v_ext, double* vpp, double* tc) {
     constexpr int G = N + 1, NB = N - 1, V = 2 * N;
     const QdLayout L = qd_layout(N);
     const double* vgm = st + L.s_vgm;
@@ -75,23 +75,60 @@ QD_HD void qd_pixel_front(const double* par, const double* st, int ch, int R, in
     for (int b = 0; b < NB; ++b) v_ext[G + b] = barrier_v[b];
 #pragma unroll
     for (int i = 0; i < G; ++i) { vpp[i] = qd_dotN<V>(par + L.cgd + i * V, v_ext); QD_ROW_FENCE(); }
-    // a8 continuous ground state
+    // a10 tunnel couplings: vb_eff = vb + Cbg @ vg (the Cbb cross term is identically 0)
+    const double tc_base = par[L.scal + 0];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        double vb_eff = barrier_v[b] + qd_dotN<G>(par + L.cbg + b * G, v_ext);
+        tc[b] = tc_base * exp(-par[L.alpha + b] * vb_eff);
+        QD_ROW_FENCE();
+    }
+}
+
+// ---------------------------------------------------------------------------
+// a8 continuous ground state, with the optional linear voltage-dependent
+// capacitance model (f4; voltage_dependent_capacitance.py:72-88, ground_state.py:53-57):
+//   cdd(V) = cdd_full (1 + alpha mean|v_ext|),  cgd(V) = cgd_full (1 + beta mean|v_ext|)
+// so, for the ground-state stage only (the sensor stage keeps the constant matrices),
+//   v' -> sb v',  A -> A / sa   with sa, sb the two scale factors.
+// Canonical form used here and in the oracle: v' is scaled, the projected-gradient step
+// uses lr = 0.1 / sa with the constant A, the search runs in the constant-A metric (a
+// positive factor does not change the order) and the kept energies are multiplied by
+// isa = 1 / sa afterwards.  With the model off sa = sb = 1 and every operation is exact,
+// so results are bit-identical to the constant-capacitance path.
+//   vd[N]: in  v' = (cgd_full @ v_ext)[:N];  out  the scaled v'.
+// ---------------------------------------------------------------------------
+template <int N>
+QD_HD void qd_pixel_continuous(const double* par, const double* v_ext, double* vd, double* ncont, double* isa) {
+    constexpr int G = N + 1, V = 2 * N;
+    const QdLayout L = qd_layout(N);
+    double sa = 1.0, sb = 1.0;
+    if (par[L.scal + 4] != 0.0) {
+        double sum = 0.0;
+#pragma unroll
+        for (int j = 0; j < V; ++j) sum += fabs(v_ext[j]);
+        const double mabs = sum / (double)V;
+        sa = fma(par[L.scal + 5], mabs, 1.0);
+        sb = fma(par[L.scal + 6], mabs, 1.0);
+    }
+    *isa = 1.0 / sa;
+    const double lr = 0.1 / sa;
     bool all_pos = true;
 #pragma unroll
-    for (int i = 0; i < N; ++i) { ncont[i] = vpp[i]; if (!(vpp[i] >= 0.0)) all_pos = false; }
+    for (int i = 0; i < N; ++i) { vd[i] = vd[i] * sb; ncont[i] = vd[i]; if (!(vd[i] >= 0.0)) all_pos = false; }
     if (!all_pos) {
         const double* A = par + L.cdd_inv;
         double n[N], g2[N], nn[N];
 #pragma unroll
-        for (int i = 0; i < N; ++i) n[i] = vpp[i] > 0.0 ? vpp[i] : 0.0;
+        for (int i = 0; i < N; ++i) n[i] = vd[i] > 0.0 ? vd[i] : 0.0;
 #pragma unroll
-        for (int i = 0; i < N; ++i) { g2[i] = qd_dotN<N>(A + i * G, vpp); QD_ROW_FENCE(); }
+        for (int i = 0; i < N; ++i) { g2[i] = qd_dotN<N>(A + i * G, vd); QD_ROW_FENCE(); }
         for (int it = 0; it < 50; ++it) {
 #pragma unroll
             for (int i = 0; i < N; ++i) {
                 double g1 = qd_dotN<N>(A + i * G, n);
                 double grad = g1 - g2[i];
-                double v = n[i] - 0.1 * grad;
+                double v = n[i] - lr * grad;
                 nn[i] = v > 0.0 ? v : 0.0;
                 QD_ROW_FENCE();
             }
@@ -103,14 +140,28 @@ QD_HD void qd_pixel_front(const double* par, const double* st, int ch, int R, in
     }
 #pragma unroll
     for (int i = 0; i < N; ++i) if (!(ncont[i] > 0.0)) ncont[i] = 0.0;
-    // a10 tunnel couplings: vb_eff = vb + Cbg @ vg (the Cbb cross term is identically 0)
-    const double tc_base = par[L.scal + 0];
+}
+
+// Whole front end (host harness / tests): vpp stays the constant-matrix product, vd is the
+// (possibly scaled) v' the candidate search uses.
+template <int N>
+QD_HD void qd_pixel_front(const double* par, const double* st, int ch, int R, int x, int y,
+                          double* v_ext, double* vpp, double* vd, double* ncont, double* tc, double* isa) {
+    qd_pixel_voltages<N>(par, st, ch, R, x, y, v_ext, vpp, tc);
 #pragma unroll
-    for (int b = 0; b < NB; ++b) {
-        double vb_eff = barrier_v[b] + qd_dotN<G>(par + L.cbg + b * G, v_ext);
-        tc[b] = tc_base * exp(-par[L.alpha + b] * vb_eff);
-        QD_ROW_FENCE();
-    }
+    for (int i = 0; i < N; ++i) vd[i] = vpp[i];
+    qd_pixel_continuous<N>(par, v_ext, vd, ncont, isa);
+}
+
+// a15 peak width of one channel: constant, or (f4, qarray_base_class.py:192-196 +
+// utils/vary_peak_width.py) clip(gamma0 - |alpha (|v_ch| + |v_ch+1|) / 2|, 0, 1) with v the
+// current VIRTUAL plunger voltages of the swept pair.
+QD_HD double qd_peak_width(const double* par, const double* st, const QdLayout& L, int ch) {
+    const double g0 = par[L.scal + 1], a = par[L.scal + 3];
+    if (a < 0.0) return g0;
+    const double vavg = (fabs(st[L.s_gate_v + ch]) + fabs(st[L.s_gate_v + ch + 1])) / 2.0;
+    const double w = g0 - fabs(a * vavg);
+    return fmin(fmax(w, 0.0), 1.0);
 }
 
 // ---------------------------------------------------------------------------
@@ -376,11 +427,10 @@ QD_HD int qd_candidates(const double* par, const double* vpp, const double* ncon
 // forms without the cancellation; agreement is to round-off (float output).
 // ---------------------------------------------------------------------------
 template <int N>
-QD_HD double qd_sensor(const double* par, const double* vpp, const double* occ) {
+QD_HD double qd_sensor(const double* par, const double* vpp, const double* occ, double gamma) {
     constexpr int G = N + 1;
     const QdLayout L = qd_layout(N);
     const double* A = par + L.cdd_inv;
-    const double gamma = par[L.scal + 1];
     const double Ns = rint(vpp[N]);                       // np.round: half to even
     double b = 0.0;
 #pragma unroll

@@ -141,7 +141,7 @@ class EpisodeBatch:
 
 
 class DeviceSampler:
-    def __init__(self, N, qcfg, ecfg):
+    def __init__(self, N, qcfg, ecfg, vary_peak_width=False, peak_width_alpha=0.01):
         self.N = N
         self.qcfg = qcfg
         self.ecfg = ecfg
@@ -155,8 +155,12 @@ class DeviceSampler:
         self.cbb_diag = float(qcfg["simulator"]["model"]["Cbb"]["diagonal"])
         if qcfg["simulator"]["model"].get("charge_carrier_type", "electrons") != "electrons":
             raise NotImplementedError("only charge_carrier_type 'electrons' (the reference default) is built")
-        if qcfg["simulator"]["voltage_capacitance_model"]["type"] is not None:
-            raise NotImplementedError("voltage-dependent capacitance (SURVEY f4) is out of scope")
+        # f4: voltage-dependent capacitances (qarray_base_class.py:840-854) and variable peak width (:856-863)
+        self.vc_type = qcfg["simulator"]["voltage_capacitance_model"]["type"]
+        if self.vc_type not in (None, "linear"):
+            raise ValueError(f"Capacitance model type '{self.vc_type}' does not exist")
+        self.vary_peak_width = bool(vary_peak_width)
+        self.peak_width_alpha = float(peak_width_alpha)
 
     # -- raw draws -> named arrays ------------------------------------------------
     def draws_from_uniform(self, u):
@@ -194,7 +198,8 @@ class DeviceSampler:
                    white_noise_amplitude=d["white_noise_amplitude"][:, 0],
                    telegraph=dict(p01=d["telegraph"][:, 0], p10=d["telegraph"][:, 1] * d["telegraph"][:, 0],
                                   amplitude=d["telegraph"][:, 2]),
-                   offset=d["offset"], radial=d["radial"])
+                   offset=d["offset"], radial=d["radial"],
+                   vc_alpha=d["vcap"][:, 0], vc_beta=d["vcap"][:, 1], vpw_alpha=d["vpw_alpha"][:, 0])
         for k in ("u_plunger_range", "u_plunger_center", "u_barrier_range", "u_barrier_center",
                   "u_start_plunger", "u_start_barrier"):
             out[k] = d[k]
@@ -271,6 +276,13 @@ class DeviceSampler:
         P[:, L.bmin:L.bmin + nb] = bmin; P[:, L.bmax:L.bmax + nb] = bmax
         P[:, L.scal + 0] = a["tc_base"]; P[:, L.scal + 1] = a["coulomb_peak_width"]
         P[:, L.scal + 2] = a["window_delta"]
+        # f4 options.  Peak width: qarray_base_class.py:856-863 (the ctor override wins unless it is the 0.01 default)
+        if self.vary_peak_width:
+            P[:, L.scal + 3] = np.abs(self.peak_width_alpha) if self.peak_width_alpha != 0.01 else a["vpw_alpha"]
+        else:
+            P[:, L.scal + 3] = -1.0
+        if self.vc_type == "linear":
+            P[:, L.scal + 4] = 1.0; P[:, L.scal + 5] = a["vc_alpha"]; P[:, L.scal + 6] = a["vc_beta"]
         # a14 latching probabilities (qarray_base_class.py:495-519)
         P[:, L.pleads:L.pleads + N] = a["p_leads"]
         P[:, L.pinter:L.pinter + N * N] = a["p_inter"].reshape(n, -1)

@@ -45,7 +45,7 @@ def layout(N: int) -> Layout:
     f = {}
     for name, n in (("cdd_inv", G * G), ("cgd", G * V), ("cbg", nb * G), ("ufac", N * N), ("uinv", N),
                     ("alpha", nb), ("origin", G), ("vopt", G), ("vbopt", nb), ("pmin", N),
-                    ("pmax", N), ("bmin", nb), ("bmax", nb), ("scal", 4), ("noise", 8), ("pleads", N), ("pinter", N * N)):
+                    ("pmax", N), ("bmin", nb), ("bmax", nb), ("scal", 8), ("noise", 8), ("pleads", N), ("pinter", N * N)):
         f[name] = o
         o += n
     f["size"] = (o + 1) & ~1

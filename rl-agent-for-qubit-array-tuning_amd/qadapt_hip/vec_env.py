@@ -45,9 +45,16 @@ class SyntheticCapacitanceModel:
 class VecQuantumDeviceEnv:
     def __init__(self, num_envs, num_dots=None, config_path=None, qarray_config_path=None,
                  resolution=None, device=None, seed=1234, env_id_offset=0, capacitance_model=None,
-                 validate=False, env_chunk=0, reset_kalman_on_reset=False, noise=None):
+                 validate=False, env_chunk=0, reset_kalman_on_reset=False, noise=None,
+                 vary_peak_width=False, peak_width_alpha=0.01, voltage_capacitance_model=None):
+        """vary_peak_width / peak_width_alpha: QarrayBaseClass ctor arguments (qarray_base_class.py:42-43).
+        voltage_capacitance_model: overrides `simulator.voltage_capacitance_model.type` of the qarray
+        config (None keeps the file's value; "linear" or "none")."""
         self.config = load_yaml(config_path, "env_config.yaml")
         self.qconfig = load_yaml(qarray_config_path, "qarray_config.yaml")
+        if voltage_capacitance_model is not None:
+            self.qconfig["simulator"]["voltage_capacitance_model"]["type"] = \
+                None if voltage_capacitance_model in ("none", "null") else voltage_capacitance_model
         sim = self.config["simulator"]
         self.num_envs = int(num_envs)
         self.num_dots = int(num_dots if num_dots is not None else sim["num_dots"])
@@ -77,7 +84,8 @@ class VecQuantumDeviceEnv:
         N = self.num_dots; R = self.resolution; B = self.num_envs
         self.N, self.R, self.B, self.C = N, R, B, N - 1
         self.L = layout(N)
-        self.sampler = DeviceSampler(N, self.qconfig, self.config)
+        self.sampler = DeviceSampler(N, self.qconfig, self.config, vary_peak_width=vary_peak_width,
+                                     peak_width_alpha=peak_width_alpha)
         self._rngs = [np.random.Generator(np.random.PCG64(seed + env_id_offset + e)) for e in range(B)]
         # ---- library handle ---------------------------------------------------
         self._lib = _lib.lib()

@@ -6,9 +6,10 @@ Run ONCE, in the build container only (needs /root/reference):
 
     python tests/golden/make_golden.py
 
-It loads two reference source files by path and executes them unmodified:
+It loads three reference source files by path and executes them unmodified:
   * src/qadapt/capacitance_model/KalmanUpdater.py        
   * src/qarray_latched/DotArrays/GateVoltageComposer.py  
+  * src/qadapt/environment/utils/vary_peak_width.py      (variable peak width)
 and stores only INPUTS and OUTPUTS (arrays) as .npz -- no reference source is
 copied.  Everything else on the hot path imports jax/qarray and cannot run
 here; those rows are pinned by analytic known-answer tests.
@@ -92,7 +93,24 @@ def sweep_grids():
     np.savez_compressed(os.path.join(HERE, "sweep_grids.npz"), **out)
 
 
+def peak_widths():
+    V = _load(f"{REF}/src/qadapt/environment/utils/vary_peak_width.py", "ref_vpw")
+    rng = np.random.default_rng(21)
+    n = 64
+    w0 = rng.uniform(0.0, 0.4, n); alpha = rng.uniform(0.0001, 0.0008, n)
+    alpha[:4] = [0.0, 0.01, -0.002, 0.05]                 # zero, the ctor default, negative, saturating
+    vx = rng.uniform(-120, 120, n); vy = rng.uniform(-120, 120, n)
+    w0[4] = 1.7                                           # clipped at the upper bound
+    out = np.array([V.VaryPeakWidth(peak_width_0=w0[i], alpha=alpha[i]).linearly_vary_peak_width(vx[i], vy[i])
+                    for i in range(n)], dtype=np.float64)
+    np.savez_compressed(os.path.join(HERE, "peak_widths.npz"), peak_width_0=w0, alpha=alpha, v_x=vx, v_y=vy, width=out)
+
+
 if __name__ == "__main__":
+    if "--only-peak-widths" in __import__("sys").argv:
+        peak_widths()
+        raise SystemExit(0)
     kalman_traces()
     sweep_grids()
+    peak_widths()
     print("golden fixtures written to", HERE)

@@ -46,6 +46,10 @@ def dev_view(N, par):
     d.n_star = np.array([1.0] * N + [0.53])
     d.window = float(par[L.scal + 2])
     d.origin = par[L.origin:L.origin + G].copy()
+    # f4 options
+    d.vpw_alpha = float(par[L.scal + 3]) if par[L.scal + 3] >= 0 else None
+    d.vc = (float(par[L.scal + 5]), float(par[L.scal + 6])) if par[L.scal + 4] != 0 else None
+    d.cdd_full = np.linalg.inv(d.cdd_inv_full) if d.vc is not None else None
     return d
 
 
@@ -83,6 +87,7 @@ def hosttest():
         subprocess.check_call(["make", "-s", "-C", hdir, "libqdsim_hosttest.so"])
         _HOST = ctypes.CDLL(os.path.join(hdir, "libqdsim_hosttest.so"))
         _HOST.qdh_sensor.restype = ctypes.c_double
+        _HOST.qdh_peak_width.restype = ctypes.c_double
     return _HOST
 
 
@@ -97,18 +102,28 @@ def host_front(N, par, st, ch, R, pix=None):
     par = np.ascontiguousarray(par); st = np.ascontiguousarray(st)
     states = np.zeros((P, 32, N), np.int32); floors = np.zeros((P, N), np.int32)
     vpp = np.zeros((P, N + 1)); tc = np.zeros((P, N - 1)); nv = np.zeros(P, np.int32)
-    stats = np.zeros(4, np.uint64)
+    stats = np.zeros(4, np.uint64); vd = np.zeros((P, N)); en = np.zeros((P, 32))
     rc = h.qdh_front(N, _p(par, ctypes.c_double), _p(st, ctypes.c_double), ch, R, p0, p1,
                      _p(states, ctypes.c_int32), _p(floors, ctypes.c_int32), _p(vpp, ctypes.c_double),
-                     _p(tc, ctypes.c_double), _p(nv, ctypes.c_int32), _p(stats, ctypes.c_uint64))
+                     _p(tc, ctypes.c_double), _p(nv, ctypes.c_int32), _p(stats, ctypes.c_uint64),
+                     _p(vd, ctypes.c_double), _p(en, ctypes.c_double))
     assert rc == 0
-    return dict(states=states, floors=floors, vpp=vpp, tc=tc, nvalid=nv, stats=stats)
+    return dict(states=states, floors=floors, vpp=vpp, tc=tc, nvalid=nv, stats=stats, vd=vd, energies=en)
 
 
-def host_sensor(N, par, vpp, occ):
+def host_peak_width(N, par, st, ch):
+    h = hosttest()
+    par = np.ascontiguousarray(par); st = np.ascontiguousarray(st)
+    return h.qdh_peak_width(N, _p(par, ctypes.c_double), _p(st, ctypes.c_double), int(ch))
+
+
+def host_sensor(N, par, vpp, occ, gamma=None):
     h = hosttest()
     par = np.ascontiguousarray(par); vpp = np.ascontiguousarray(vpp); occ = np.ascontiguousarray(occ)
-    return h.qdh_sensor(N, _p(par, ctypes.c_double), _p(vpp, ctypes.c_double), _p(occ, ctypes.c_double))
+    if gamma is None:
+        gamma = float(par[layout(N).scal + 1])
+    return h.qdh_sensor(N, _p(par, ctypes.c_double), _p(vpp, ctypes.c_double), _p(occ, ctypes.c_double),
+                        ctypes.c_double(gamma))
 
 
 def host_layout(N):

@@ -11,14 +11,16 @@
 template <int N>
 static int run_front(const double* par, const double* st, int ch, int R, int p0, int p1,
                      int32_t* states, int32_t* floors, double* vpp_out, double* tc_out,
-                     int32_t* nvalid, unsigned long long* stats) {
+                     int32_t* nvalid, unsigned long long* stats, double* vd_out, double* e_out) {
     constexpr int G = N + 1, NB = N - 1, V = 2 * N;
     for (int p = p0; p < p1; ++p) {
         int y = p / R, x = p % R;
-        double v_ext[V], vpp[G], ncont[N], tc[NB > 0 ? NB : 1];
-        qd_pixel_front<N>(par, st, ch, R, x, y, v_ext, vpp, ncont, tc);
+        double v_ext[V], vpp[G], vd[N], ncont[N], tc[NB > 0 ? NB : 1], isa;
+        qd_pixel_front<N>(par, st, ch, R, x, y, v_ext, vpp, vd, ncont, tc, &isa);
         double e[QD_K]; uint16_t id[QD_K]; int32_t fl[N];
-        int nv = qd_candidates<N>(par, vpp, ncont, e, 1, id, 1, fl, true, stats);
+        int nv = qd_candidates<N>(par, vd, ncont, e, 1, id, 1, fl, true, stats);
+        if (vd_out) memcpy(vd_out + (size_t)p * N, vd, sizeof(double) * N);
+        if (e_out) for (int m = 0; m < QD_K; ++m) e_out[(size_t)p * QD_K + m] = m < nv ? e[m] * isa : 0.0;
         static const int DELTA[4] = {-1, 0, 1, 2};
         for (int m = 0; m < QD_K; ++m)
             for (int i = 0; i < N; ++i) {
@@ -35,18 +37,22 @@ static int run_front(const double* par, const double* st, int ch, int R, int p0,
 
 extern "C" int qdh_front(int N, const double* par, const double* st, int ch, int R, int p0, int p1,
                          int32_t* states, int32_t* floors, double* vpp_out, double* tc_out,
-                         int32_t* nvalid, unsigned long long* stats) {
+                         int32_t* nvalid, unsigned long long* stats, double* vd_out, double* e_out) {
     switch (N) {
-#define C(n) case n: return run_front<n>(par, st, ch, R, p0, p1, states, floors, vpp_out, tc_out, nvalid, stats);
+#define C(n) case n: return run_front<n>(par, st, ch, R, p0, p1, states, floors, vpp_out, tc_out, nvalid, stats, vd_out, e_out);
         C(2) C(3) C(4) C(5) C(6) C(7) C(8)
 #undef C
     }
     return 1;
 }
 
-extern "C" double qdh_sensor(int N, const double* par, const double* vpp, const double* occ) {
+extern "C" double qdh_peak_width(int N, const double* par, const double* st, int ch) {
+    return qd_peak_width(par, st, qd_layout(N), ch);
+}
+
+extern "C" double qdh_sensor(int N, const double* par, const double* vpp, const double* occ, double gamma) {
     switch (N) {
-#define C(n) case n: return qd_sensor<n>(par, vpp, occ);
+#define C(n) case n: return qd_sensor<n>(par, vpp, occ, gamma);
         C(2) C(3) C(4) C(5) C(6) C(7) C(8)
 #undef C
     }
