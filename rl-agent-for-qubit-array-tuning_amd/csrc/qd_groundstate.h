@@ -40,6 +40,13 @@
 #define QD_NBREG 3                  // neighbour slots kept in registers for the matvecs
 #endif
 
+// LDS-qualified volatile pointers: a plain `volatile double*` into __shared__ memory stays a generic
+// pointer (address-space inference skips volatile accesses) and every access becomes a FLAT load;
+// with the address space spelled out they are ds_read / ds_write.
+typedef __attribute__((address_space(3))) double qd_lds_double;
+typedef volatile qd_lds_double* qd_lds_vptr;
+typedef const volatile qd_lds_double* qd_lds_cvptr;
+
 struct QdWaveLds {
     double coef[QD_NBMAX - QD_NBREG][64];      // H_ij of neighbour slots QD_NBREG.. of lane (the first QD_NBREG live in registers)
     unsigned char nidx[QD_NBMAX - QD_NBREG][64];
@@ -48,7 +55,7 @@ struct QdWaveLds {
     double rd[64], lf[64], yv[64];  // inverse iteration: 1/d_i, l_i, y_i at member slots
     double ib[64];                  // 1/beta_r at the r-th member lane (pass-2 replay)
     double pv[2][16];               // per half: vpp[0..N] (cgd @ v_ext) then tc[0..N-2] at offset 9
-    int pfl[2][8];                  // per half: floor(n_cont)
+    short pfl[2][8];                // per half: floor(n_cont) (|n| < 2^15 by a wide margin; 16-bit keeps 4 blocks per CU within 160 KB)
 };
 
 __device__ __forceinline__ unsigned qd_half_ballot(bool p) {
@@ -99,7 +106,7 @@ struct QdMembers {
     int nrest_max;       // wave-wide max count of such members
 };
 
-__device__ __forceinline__ double qd_seg_sum(double v, const QdMembers& M, volatile double* buf, int hb) {
+__device__ __forceinline__ double qd_seg_sum(double v, const QdMembers& M, qd_lds_vptr buf, int hb) {
     buf[threadIdx.x & 63] = v;
     __builtin_amdgcn_wave_barrier();
     double acc = 0.0;
@@ -112,7 +119,7 @@ __device__ __forceinline__ double qd_seg_sum(double v, const QdMembers& M, volat
     __builtin_amdgcn_wave_barrier();
     return acc;
 }
-__device__ __forceinline__ double qd_seg_min(double v, const QdMembers& M, int ssz, volatile double* buf, int hb) {
+__device__ __forceinline__ double qd_seg_min(double v, const QdMembers& M, int ssz, qd_lds_vptr buf, int hb) {
     buf[threadIdx.x & 63] = v;
     __builtin_amdgcn_wave_barrier();
     double acc = INFINITY;
@@ -125,7 +132,7 @@ __device__ __forceinline__ double qd_seg_min(double v, const QdMembers& M, int s
     __builtin_amdgcn_wave_barrier();
     return acc;
 }
-__device__ __forceinline__ double qd_seg_max(double v, const QdMembers& M, int ssz, volatile double* buf, int hb) {
+__device__ __forceinline__ double qd_seg_max(double v, const QdMembers& M, int ssz, qd_lds_vptr buf, int hb) {
     return -qd_seg_min(-v, M, ssz, buf, hb);
 }
 
@@ -138,14 +145,14 @@ __device__ void qd_ground_pixel(const QdPixelRec* __restrict__ rec, QdWaveLds& W
     const int m = lane & 31;
     const int hb = lane & 32;
     const unsigned lt = (1u << m) - 1u;
-    volatile double* buf = W.buf;
+    qd_lds_vptr buf = (qd_lds_vptr)W.buf;
 
     // ---- 1. my state -------------------------------------------------------
     // pixel-uniform record fields go through LDS once (keeps them out of registers)
     const int hh = hb >> 5;
     if (m < N + 1) W.pv[hh][m] = rec->vpp[m];
     else if (m >= 9 && m < 9 + N - 1) W.pv[hh][m] = rec->tc[m - 9];
-    if (m >= 16 && m < 16 + N) W.pfl[hh][m - 16] = rec->fl[m - 16];
+    if (m >= 16 && m < 16 + N) W.pfl[hh][m - 16] = (short)rec->fl[m - 16];
     __builtin_amdgcn_wave_barrier();
     const double* pvv = W.pv[hh];
     const int nvalid = rec->nvalid;
@@ -301,8 +308,8 @@ __device__ void qd_ground_pixel(const QdPixelRec* __restrict__ rec, QdWaveLds& W
     W.be[lane] = (r < k - 1) ? be_mine : 0.0;
     W.ib[lane] = ib_mine;
     __builtin_amdgcn_wave_barrier();
-    volatile const double* al = W.al;
-    volatile const double* be = W.be;
+    qd_lds_cvptr al = (qd_lds_cvptr)W.al;
+    qd_lds_cvptr be = (qd_lds_cvptr)W.be;
     const int kmax = qd_wave_max_int(k);
 
     // ---- 6a. lowest eigenvalue of T: Laguerre iteration from the left ----------
