@@ -176,16 +176,25 @@ __device__ void qd_ground_pixel(const QdPixelRec* __restrict__ rec, QdWaveLds& W
     unsigned tcnz = 0;
 #pragma unroll
     for (int d = 0; d < N - 1; ++d) tcnz |= (pvv[9 + d] != 0.0 ? 1u : 0u) << d;
+    // nibble q of ecode is the digit of dot N-1-q.  (cj | 0x8..8) - ecode holds 8 + (digit_j - digit_i)
+    // in every nibble (no borrows), so Z = that ^ 0x8..8 has nibble 0 where the digits agree, 1 for +1
+    // and 0xF for -1: j is a hop neighbour iff Z == 0x1F << 4q or 0xF1 << 4q (one electron moved
+    // between the adjacent dots of pair N-2-q) and that pair's coupling is non-zero.
+    unsigned tcq = 0;                                     // bit 4q set iff pair N-2-q couples
+#pragma unroll
+    for (int q = 0; q < N - 1; ++q) tcq |= ((tcnz >> (N - 2 - q)) & 1u) << (4 * q);
     unsigned nbrmask = 0;
 #pragma unroll 4
     for (int j = 0; j < 32; ++j) {
         const unsigned cj = __shfl(ecode, j, 32);
-        const int Y = (int)cj - (int)ecode;
-        const unsigned ay = (unsigned)(Y < 0 ? -Y : Y);
-        const int tz = ay ? __builtin_ctz(ay) : 0;
-        const bool hop = ay != 0 && (ay >> tz) == 15u && (tz & 3) == 0 && ((tcnz >> (N - 2 - (tz >> 2))) & 1u);
-        if (hop && valid && j < nvalid) nbrmask |= 1u << j;
+        const unsigned Z = ((cj | 0x88888888u) - ecode) ^ 0x88888888u;
+        const int tz = __builtin_ctz(Z | 0x80000000u);     // Z == 0 (same state): tz = 31, Zs = 0, no hop (a nibble of Z is never 8)
+        const unsigned Zs = Z >> tz;
+        const bool hop = (Zs == 0x1Fu || Zs == 0xF1u) && ((tcq >> tz) & 1u);
+        if (hop) nbrmask |= 1u << j;
     }
+    // states beyond the valid count (|0..0> padding) neither hop nor are hopped to
+    nbrmask = valid ? (nbrmask & (nvalid >= 32 ? 0xFFFFFFFFu : ((1u << nvalid) - 1u))) : 0u;
 #if defined(QD_ABLATE) && QD_ABLATE == 4
     nbrmask = 0;                                          // diagnostic: no hopping at all
 #endif

@@ -201,7 +201,7 @@ qd_k_candidates(const int* __restrict__ env_ids, int env_base, int R, const doub
 #define QD_GS_PPB 64            // pixels per block: 8 half-waves x 8 pixels
 
 #ifndef QD_GS_WAVES
-#define QD_GS_WAVES 3
+#define QD_GS_WAVES 4            // <= 128 VGPRs (no spills since the LDS pointers are address-space qualified) and 4 x 40 896 B of LDS per CU
 #endif
 template <int N>
 __global__ void __launch_bounds__(QD_GS_BLOCK, QD_GS_WAVES)
