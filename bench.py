@@ -47,6 +47,16 @@ def f_alg(N, R):
     return per_pixel * (N - 1) * R * R
 
 
+def valu_busy(N, R):
+    f = os.path.join(ROOT, "profiles", "valu_busy.json")
+    if not os.path.exists(f):
+        return None
+    d = json.load(open(f))
+    out = {k.split("_")[0]: round(v["valu_busy_frac"], 3) for k, v in d.items()
+           if isinstance(v, dict) and k.endswith(f"_{N}dot_{R}")}
+    return out or None
+
+
 def cpu_baseline(N, R, seconds_budget=20.0):
     """The plain-C oracle (literal reference algorithm, OpenMP) on the host cores,
     on a bounded sample: whole channels of one env until the budget is used."""
@@ -184,10 +194,13 @@ def main():
             # (4^N-candidate scan + dense 32x32 eigh per pixel); the kernels do far less work than that
             # (exact k-best search, block-wise Lanczos), so the "literal-equivalent" rate may exceed the
             # float64 vector peak -- it measures algorithmic savings, not pipeline utilisation (measured
-            # VALU utilisation of the ground kernel is ~50 %, profiles/r01_b_pmc_summary.csv).
+            # VALU issue utilisation: see measured_issue_utilisation).
             "valu": {"literal_flops_per_env_step": f_alg(N, R),
                      "literal_equivalent_tflops": f_alg(N, R) * value / world / 1e12,
-                     "fp64_vector_peak_tflops": FP64_VECTOR_PEAK_TFLOPS},
+                     "fp64_vector_peak_tflops": FP64_VECTOR_PEAK_TFLOPS,
+                     # measured vector-ALU issue utilisation of the two kernels (rocprofv3 SQ counters,
+                     # profiles/valu_busy.json): the roofline that actually bounds this path
+                     "measured_issue_utilisation": valu_busy(N, R)},
         }
         if not args.no_cpu_baseline and world == 1:          # reported at N = 1 only
             out["cpu_baseline"] = cpu_baseline(N, R, args.cpu_seconds)
