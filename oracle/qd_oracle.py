@@ -19,6 +19,10 @@ Parity status
 * Everything else (a6-a15, a17, a20-a23) is **parity unpinned** against the
   reference binary: it is pinned by line-by-line restatement (citations below)
   plus analytic known-answer tests (tests/test_oracle_known_answers.py).
+* Rows f3/f4 (added later): `utils/vary_peak_width.py` imports standalone and pins the
+  variable peak width (`tests/golden/peak_widths.npz`); the linear voltage-dependent
+  capacitance model (jax) and the RLlib frame-stacking connector (ray) are literal
+  restatements, **parity unpinned**.
 * The stochastic parts that live in third-party `qarray==1.6.0`
   (LatchingModel.add_latching, WhiteNoise/TelegraphNoise) are not restated
   here: deterministic parity is defined with latching off and noise amplitudes 0.
@@ -731,3 +735,50 @@ class OracleEnv:
         self._kalman_and_vgm(cnn_values, cnn_log_vars)
         self.gate_gt, self.barrier_gt, self.sensor_gt = ground_truth(self.dev, self.vgm, self.origin)
         return obs, rew, False, truncated
+
+
+# --------------------------------------------------------------------------
+# f3  frame stacking connector, literal list-based restatement
+#     (training/utils/custom_frame_stacking.py:184-249 env-to-module,
+#      :90-182 learner pipeline).  Test infrastructure like the rest of this file.
+# --------------------------------------------------------------------------
+def frame_stack_env_to_module(obs_list, num_frames):
+    """obs_list: the running episode's observations of ONE plunger agent, oldest first, each
+    {"image": (H,W,C), "voltage": (1,)}.  Returns the stacked observation of the latest step."""
+    obs_stack = obs_list[-num_frames:]
+    images = [o["image"] for o in obs_stack]
+    voltages = [o["voltage"] for o in obs_stack]
+    actual = len(images)
+    if actual >= num_frames:
+        stacked_images = np.stack(images[-num_frames:], axis=0)
+        stacked_voltages = np.array([v[0] for v in voltages[-num_frames:]], dtype=np.float32)
+        mask = np.zeros(num_frames, dtype=np.int8)
+    else:
+        num_padding = num_frames - actual
+        H, W, C = images[0].shape
+        padded_images = [np.zeros((H, W, C), dtype=images[0].dtype) for _ in range(num_padding)] + images
+        padded_voltages = [0.0] * num_padding + [v[0] for v in voltages]
+        stacked_images = np.stack(padded_images, axis=0)
+        stacked_voltages = np.array(padded_voltages, dtype=np.float32)
+        mask = np.array([True] * num_padding + [False] * actual, dtype=np.int8)
+    return {"image": stacked_images, "voltage": stacked_voltages, "attention_mask": mask}
+
+
+def frame_stack_learner(images, voltages, num_frames):
+    """images (A,H,W,C), voltages (A,1): what `get_observations(slice(-num_frames+1, len), fill=None)`
+    returned -- the episode's T observations preceded by whatever look-back exists (A >= T is not
+    required).  T is passed implicitly as A - lookback; here lookback = 0, i.e. A == T."""
+    T = images.shape[0]
+    H, W, C = images.shape[1:]
+    required = T + num_frames - 1
+    num_padding = required - T
+    padded_images = np.concatenate([np.zeros((num_padding, H, W, C), dtype=images.dtype), images], axis=0)
+    padded_voltages = np.concatenate([np.zeros((num_padding,), dtype=voltages.dtype), voltages.squeeze(-1)], axis=0)
+    out_i = np.stack([padded_images[t:t + num_frames] for t in range(T)])
+    out_v = np.stack([padded_voltages[t:t + num_frames] for t in range(T)])
+    mask = np.zeros((T, num_frames), dtype=np.int8)
+    for t in range(T):
+        for f in range(num_frames):
+            if t + f < num_padding:
+                mask[t, f] = True
+    return {"image": out_i, "voltage": out_v, "attention_mask": mask}
