@@ -372,11 +372,33 @@ __device__ void qd_ground_pixel(const QdPixelRec* __restrict__ rec, QdWaveLds& W
                 if (ap_ > 1e100) sc_ = 1e-100; else if (ap_ < 1e-100 && ap_ > 0.0) sc_ = 1e100; \
                 if (sc_ != 1.0) { p0 *= sc_; p1 *= sc_; d0 *= sc_; d1 *= sc_; e0 *= sc_; e1 *= sc_; } \
             }
+            // Unrolled rows 0..7 ping-pong between the two register sets (even rows overwrite the "older"
+            // set 0, odd rows set 1) instead of rotating p0 <- p1 <- p2: inside predicated blocks the
+            // rotation costs six 64-bit moves per row.  After an even number of rows the roles are the
+            // usual ones (set 1 = current), which is what the dynamic tail loop below relies on (only
+            // lanes with k > 8 enter it); lanes that stopped after an odd k < 8 are fixed up afterwards.
+#define QD_LAG_ROW_PP(AL, BE, FIRST, PO, PC, DO, DC, EO, EC)                        \
+            {                                                                       \
+                const double a_ = (AL) - xl;                                        \
+                const double b2_ = bprev * bprev;                                   \
+                if (FIRST) { PO = a_; DO = -1.0; EO = 0.0; }                        \
+                else {                                                              \
+                    const double pn_ = fma(a_, PC, -(b2_ * PO));                    \
+                    const double dn_ = fma(a_, DC, -(b2_ * DO)) - PC;               \
+                    const double en_ = fma(a_, EC, -(b2_ * EO)) - 2.0 * DC;         \
+                    PO = pn_; DO = dn_; EO = en_;                                   \
+                }                                                                   \
+                bprev = (BE);                                                       \
+            }
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                if (i < k) { QD_LAG_ROW(al[MB.idx[i]], be[MB.idx[i]], i == 0) }
+                if (i < k) {
+                    if (i & 1) { QD_LAG_ROW_PP(al[MB.idx[i]], be[MB.idx[i]], false, p1, p0, d1, d0, e1, e0) }
+                    else       { QD_LAG_ROW_PP(al[MB.idx[i]], be[MB.idx[i]], i == 0, p0, p1, d0, d1, e0, e1) }
+                }
                 if ((i & 3) == 3) QD_LAG_RESCALE()
             }
+#undef QD_LAG_ROW_PP
             {
                 unsigned mm = MB.rest;
                 for (int i = 8; i < kmax; ++i) {
@@ -387,6 +409,7 @@ __device__ void qd_ground_pixel(const QdPixelRec* __restrict__ rec, QdWaveLds& W
                     if ((i & 3) == 3) QD_LAG_RESCALE()
                 }
             }
+            if (k < 8 && (k & 1)) { p1 = p0; d1 = d0; e1 = e0; }      // odd row count: the current values sit in set 0
 #undef QD_LAG_ROW
 #undef QD_LAG_RESCALE
             if (!conv) {
@@ -395,10 +418,12 @@ __device__ void qd_ground_pixel(const QdPixelRec* __restrict__ rec, QdWaveLds& W
                     const double ip = qd_rcp(p1);
                     const double G = d1 * ip, E = e1 * ip;
                     double disc = (dk - 1.0) * ((dk - 1.0) * G * G - dk * E);
-                    if (!(disc > 0.0)) disc = 0.0;
-                    const double sq = sqrt(disc);
+                    // the iterate needs no correctly rounded sqrt / quotient (the fixed point does not depend
+                    // on them): rsq + Newton and rcp + Newton are a third of the IEEE sequences' instructions
+                    double sq = 0.0, rs_ = 0.0;
+                    if (disc > 0.0) qd_sqrt_rsqrt(disc, sq, rs_);
                     const double den = (G < 0.0) ? G - sq : G + sq;
-                    const double xn = (den != 0.0) ? xl - dk / den : xl;
+                    const double xn = (den != 0.0) ? fma(-dk, qd_rcp(den), xl) : xl;
                     if (!(xn > xl)) conv = true;                       // monotone sequence has stalled
                     else {
                         if (xn - xl <= 4e-16 * fmax(fabs(xn), fabs(xl))) conv = true;
