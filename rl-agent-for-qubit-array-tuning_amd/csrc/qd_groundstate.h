@@ -137,8 +137,8 @@ __device__ __forceinline__ double qd_seg_max(double v, const QdMembers& M, int s
 }
 
 // One pixel per half-wave.  A: cdd_inv (row-major, lda = N+1) readable by all
-// lanes (LDS).  rec: this half's pixel record.  On return every lane of the half
-// holds the expectation occupations occ[0..N) and the ground energy.
+// lanes (LDS).  rec: this half's pixel record.  On return lane m of the half holds the
+// expectation occupation of dot (m >> 2) & 7 (0 for dots >= N) and every lane the ground energy.
 template <int N>
 __device__ void qd_ground_pixel(const QdPixelRec* __restrict__ rec, QdWaveLds& W, double* occ, double* lam_out) {
     const int lane = threadIdx.x & 63;
@@ -288,12 +288,17 @@ __device__ void qd_ground_pixel(const QdPixelRec* __restrict__ rec, QdWaveLds& W
     const int jmax = qd_wave_max_int(solve ? ssz : 0);
     for (int j = 0; j < jmax; ++j) {
         if (!__any(!done)) break;
+        // matvec: q is published once and every neighbour's entry is one 64-bit LDS read (a 64-bit
+        // cross-lane shuffle would be two ds_bpermute each); LDS operations of a wave complete in order,
+        // so the reduction below may overwrite the buffer without another barrier
         double w = F * q;
+        buf[lane] = q;
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int i = 0; i < QD_NBREG; ++i)
-            if (i < maxcnt) { const double qj = __shfl(q, nbi[i], 32); w = fma(nbc[i], qj, w); }
+            if (i < maxcnt) { const double qj = buf[hb + nbi[i]]; w = fma(nbc[i], qj, w); }
         for (int s = QD_NBREG; s < maxcnt; ++s) {
-            const double qj = __shfl(q, (int)W.nidx[s - QD_NBREG][lane], 32);
+            const double qj = buf[hb + (int)W.nidx[s - QD_NBREG][lane]];
             w = fma(W.coef[s - QD_NBREG][lane], qj, w);
         }
         const double a = qd_seg_sum(q * w, MB, buf, hb);
@@ -529,13 +534,16 @@ __device__ void qd_ground_pixel(const QdPixelRec* __restrict__ rec, QdWaveLds& W
             double yj = 0.0, a = 0.0, b = 0.0, ib = 0.0;
             if (!done2) { const int bb = __builtin_ctz(mm); mm &= mm - 1; yj = W.yv[hb + bb]; a = al[hb + bb]; b = be[hb + bb]; ib = W.ib[hb + bb]; }
             double w = F * q2;
+            buf[lane] = q2;
+            __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int i = 0; i < QD_NBREG; ++i)
-                if (i < maxcnt) { const double qj = __shfl(q2, nbi[i], 32); w = fma(nbc[i], qj, w); }
+                if (i < maxcnt) { const double qj = buf[hb + nbi[i]]; w = fma(nbc[i], qj, w); }
             for (int s = QD_NBREG; s < maxcnt; ++s) {
-                const double qj = __shfl(q2, (int)W.nidx[s - QD_NBREG][lane], 32);
+                const double qj = buf[hb + (int)W.nidx[s - QD_NBREG][lane]];
                 w = fma(W.coef[s - QD_NBREG][lane], qj, w);
             }
+            __builtin_amdgcn_wave_barrier();
             w = w - a * q2 - bp2 * qp2;
             if (!done2) {
                 x = fma(yj, q2, x);
@@ -562,8 +570,31 @@ __device__ void qd_ground_pixel(const QdPixelRec* __restrict__ rec, QdWaveLds& W
     const int wroot = __builtin_ctz(win);
     const unsigned wseg = __shfl(seg, wroot, 32);
     const double p = ((wseg >> m) & 1u) ? x * x : 0.0;
+    // <n_i> = sum_m p_m n_m[i] for all dots at once by a reduce-scatter butterfly: each exchange halves
+    // the number of partial sums a lane carries (4 + 2 + 1 exchanges), two more finish the single sum
+    // left -- 9 cross-lane exchanges instead of 5 per dot.  Lane m ends up with dot (m >> 2) & 7.
+    double v[8];
 #pragma unroll
-    for (int i = 0; i < N; ++i) occ[i] = qd_half_sum(p * (double)n[i]);
+    for (int i = 0; i < 8; ++i) v[i] = (i < N) ? p * (double)n[i] : 0.0;
+    {
+        const bool b4 = (m & 16) != 0, b3 = (m & 8) != 0, b2 = (m & 4) != 0;
+        double w4[4], w2[2];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const double send = b4 ? v[j] : v[j + 4], keep = b4 ? v[j + 4] : v[j];
+            w4[j] = keep + __shfl_xor(send, 16, 32);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const double send = b3 ? w4[j] : w4[j + 2], keep = b3 ? w4[j + 2] : w4[j];
+            w2[j] = keep + __shfl_xor(send, 8, 32);
+        }
+        const double send = b2 ? w2[0] : w2[1], keep = b2 ? w2[1] : w2[0];
+        double w1 = keep + __shfl_xor(send, 4, 32);
+        w1 += __shfl_xor(w1, 2, 32);
+        w1 += __shfl_xor(w1, 1, 32);
+        *occ = w1;
+    }
     *lam_out = best;
 }
 

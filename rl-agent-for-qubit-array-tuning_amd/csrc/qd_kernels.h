@@ -230,23 +230,27 @@ qd_k_ground(const int* __restrict__ env_ids, int env_base, int R, const double* 
         const int pc = p < P ? p : P - 1;
         if (p0 + it * 8 >= P) break;                         // uniform for the block
         const QdPixelRec* rec = rbase + pc;
-        double occ[N], lam;
-        qd_ground_pixel<N>(rec, W, occ, &lam);
-        if ((threadIdx.x & 31) == 0 && p < P) {
+        double occ, lam;
+        qd_ground_pixel<N>(rec, W, &occ, &lam);
+        {
             // hand the sensor stage (qd_k_sensor) the pixel's constant c0 = 2 b + a (2 (Ns - v''_s) + 1):
-            // F_{k+1} - F_k = c0 + 2 a (k + eta)   (closed form of the reference's energy differences)
+            // F_{k+1} - F_k = c0 + 2 a (k + eta)   (closed form of the reference's energy differences).
+            // Lane m holds <n_i> of dot i = (m >> 2) & 7: b = sum_i A[N][i] (<n_i> - v''_i) is three more exchanges.
+            const int m = threadIdx.x & 31;
+            const int i = (m >> 2) & 7;
             const double* pvv = W.pv[(threadIdx.x >> 5) & 1];
-            const double vs = pvv[N];
-            const double Ns = rint(vs);                                 // np.round: half to even
-            double b = 0.0;
-#pragma unroll
-            for (int i = 0; i < N; ++i) b = fma(par[L.cdd_inv + N * G + i], occ[i] - pvv[i], b);   // block-uniform: scalar loads
-            const double a = par[L.cdd_inv + N * G + N];
-            zraw[((size_t)e * (N - 1) + ch) * P + p] = 2.0 * b + a * (2.0 * (Ns - vs) + 1.0);
-            if (occ_out) {
-#pragma unroll
-                for (int i = 0; i < N; ++i) occ_out[(((size_t)e * (N - 1) + ch) * P + p) * N + i] = occ[i];
+            double b = (i < N) ? par[L.cdd_inv + N * G + i] * (occ - pvv[i]) : 0.0;
+            b += __shfl_xor(b, 4, 32);
+            b += __shfl_xor(b, 8, 32);
+            b += __shfl_xor(b, 16, 32);
+            if (m == 0 && p < P) {
+                const double vs = pvv[N];
+                const double Ns = rint(vs);                             // np.round: half to even
+                const double a = par[L.cdd_inv + N * G + N];
+                zraw[((size_t)e * (N - 1) + ch) * P + p] = 2.0 * b + a * (2.0 * (Ns - vs) + 1.0);
             }
+            if (occ_out && (m & 3) == 0 && i < N && p < P)
+                occ_out[(((size_t)e * (N - 1) + ch) * P + p) * N + i] = occ;
         }
     }
 }
