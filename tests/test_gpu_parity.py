@@ -507,3 +507,38 @@ def test_nan_inputs_give_zero_image_not_a_hang():
     assert np.isnan(plohi[1]).all() and np.all(img[1] == 0)
     assert np.isfinite(raw[0]).all() and np.isfinite(img[0]).all() and img[0].max() == 1.0
     env.close()
+
+
+@pytest.mark.parametrize("N,R,B,chunk", [(4, 16, 5, 2), (8, 8, 7, 3)])
+def test_chunked_launches_are_bit_identical_to_one_launch(N, R, B, chunk):
+    """The hot kernels run over `env_chunk` envs per launch (a 4096-env batch is 54 launches): the
+    chunking -- including a ragged last chunk and a partial reset through an env-id list -- must not
+    change a single bit of any output.  (Validate mode keeps every env's records and therefore
+    always runs one launch, so both handles are product-mode ones; validate vs product is a different
+    lane order and only agrees to round-off, see test_product_mode_matches_validate_mode.)"""
+    import torch
+    from qadapt_hip.vec_env import VecQuantumDeviceEnv, SyntheticCapacitanceModel
+    mk = lambda **kw: VecQuantumDeviceEnv(B, num_dots=N, resolution=R, seed=31, capacitance_model=SyntheticCapacitanceModel(7), **kw)
+    one = mk(env_chunk=B); many = mk(env_chunk=chunk)
+    assert many.chunk_envs() == chunk and one.chunk_envs() == B
+    envs = (one, many)
+    for env in envs:
+        env.reset()
+    rng = np.random.default_rng(4)
+    for step in range(2):
+        act = torch.as_tensor(rng.uniform(-0.3, 0.3, (B, 2 * N - 1)).astype(np.float32)).cuda()
+        outs = []
+        for env in envs:
+            obs, rew, term, trunc = env.step(act)
+            outs.append((obs["image"].cpu().numpy().copy(), rew.cpu().numpy().copy(), env.raw()[0].copy(),
+                         obs["plunger_images"].cpu().numpy().copy(), obs["barrier_images"].cpu().numpy().copy()))
+        for a, b in zip(*outs):
+            assert np.array_equal(a, b)
+    # partial reset of a non-contiguous env subset (qd_observe with an id list, chunked)
+    ids = [0, 2, B - 1]
+    for env in envs:
+        env.reset(env_ids=ids, seed=99)
+    assert np.array_equal(one.global_image.cpu().numpy(), many.global_image.cpu().numpy())
+    assert np.array_equal(one.get_state()[0], many.get_state()[0])
+    for env in envs:
+        env.close()
