@@ -9,10 +9,11 @@
 //
 // Algorithm (numerics validated against numpy.linalg.eigh in
 // tests/proto_groundstate.py, which this file follows step by step):
-//   1. occupations and free energy F_m of lane m's state (canonical energy()).
+//   1. occupations of lane m's state; its free energy F_m comes with the record (the candidates
+//      kernel evaluated the canonical energy of every kept state).
 //   2. hop neighbours: states i,j are coupled over the adjacent pair d iff
-//      s_j - s_i = -+e_d +-e_{d+1}.  With 4-bit-spaced delta codes that is
-//      |code_j - code_i| == 15 << 4q.  H_ij = -t_d sqrt(n_from (n_to + 1)) with
+//      s_j - s_i = -+e_d +-e_{d+1}.  With 4-bit-spaced delta codes that is a borrow-free nibble
+//      difference of 0x1F << 4q or 0xF1 << 4q.  H_ij = -t_d sqrt(n_from (n_to + 1)) with
 //      the occupations of the ROW state (hamiltonian_build.py:125-131).
 //   3. connected components of that graph (hopping conserves total charge, so H
 //      is block diagonal; the padding copies of |0..0> are always isolated).
@@ -136,8 +137,8 @@ __device__ __forceinline__ double qd_seg_max(double v, const QdMembers& M, int s
     return -qd_seg_min(-v, M, ssz, buf, hb);
 }
 
-// One pixel per half-wave.  A: cdd_inv (row-major, lda = N+1) readable by all
-// lanes (LDS).  rec: this half's pixel record.  On return lane m of the half holds the
+// One pixel per half-wave.  rec: this half's pixel record (states, their free energies from the
+// candidates kernel, v'', tunnel couplings).  On return lane m of the half holds the
 // expectation occupation of dot (m >> 2) & 7 (0 for dots >= N) and every lane the ground energy.
 template <int N>
 __device__ void qd_ground_pixel(const QdPixelRec* __restrict__ rec, QdWaveLds& W, double* occ, double* lam_out) {
