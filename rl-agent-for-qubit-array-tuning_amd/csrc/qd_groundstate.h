@@ -352,6 +352,7 @@ __device__ void qd_ground_pixel(const QdPixelRec* __restrict__ rec, QdWaveLds& W
         bool conv = k <= 1;
 #endif
         const double dk = (double)k;
+        const bool huge_scale = __any(tscale > 1e30);
         for (int it = 0; it < 48; ++it) {
             if (!__any(!conv)) break;
             // p, p', p'' at xl: three-term recurrences over the rows of T.  The first 8 rows use the
@@ -402,7 +403,9 @@ __device__ void qd_ground_pixel(const QdPixelRec* __restrict__ rec, QdWaveLds& W
                     if (i & 1) { QD_LAG_ROW_PP(al[MB.idx[i]], be[MB.idx[i]], false, p1, p0, d1, d0, e1, e0) }
                     else       { QD_LAG_ROW_PP(al[MB.idx[i]], be[MB.idx[i]], i == 0, p0, p1, d0, d1, e0, e1) }
                 }
-                if ((i & 3) == 3) QD_LAG_RESCALE()
+                // eight rows grow the minors by at most (2 tscale)^8 from 1: one rescale at the end is enough
+                // unless the matrix scale itself is astronomic (wave-uniform test)
+                if (i == 7 || (i == 3 && huge_scale)) QD_LAG_RESCALE()
             }
 #undef QD_LAG_ROW_PP
             {
