@@ -116,6 +116,9 @@ QD_HD void qd_pixel_continuous(const double* par, const double* v_ext, double* v
     bool all_pos = true;
 #pragma unroll
     for (int i = 0; i < N; ++i) { vd[i] = vd[i] * sb; ncont[i] = vd[i]; if (!(vd[i] >= 0.0)) all_pos = false; }
+#if defined(QD_CAND_ABLATE) && QD_CAND_ABLATE == 1
+    all_pos = true;                                        // diagnostic: skip the projected-gradient loop
+#endif
     if (!all_pos) {
         const double* A = par + L.cdd_inv;
         double n[N], g2[N], nn[N];
@@ -409,7 +412,9 @@ QD_HD int qd_candidates(const double* par, const double* vpp, const double* ncon
     S.e = e; S.es = es; S.id = id; S.is = is;
     S.count = 0; S.lim = INFINITY; S.idx = 0;
     S.nodes = S.leaves = S.inserts = S.shifts = 0;
-    QdLevel<N, 0>::run(S, 0.0);
+#if !(defined(QD_CAND_ABLATE) && QD_CAND_ABLATE == 2)
+    QdLevel<N, 0>::run(S, 0.0);                            // (ablate 2: diagnostic, front end only)
+#endif
     if (sort_output) qd_search_sort(S);
 #ifndef __HIP_DEVICE_COMPILE__
     if (stats) { stats[0] += S.nodes; stats[1] += S.leaves; stats[2] += S.inserts; stats[3] += S.shifts; }
