@@ -542,3 +542,37 @@ def test_chunked_launches_are_bit_identical_to_one_launch(N, R, B, chunk):
     assert np.array_equal(one.get_state()[0], many.get_state()[0])
     for env in envs:
         env.close()
+
+
+@pytest.mark.parametrize("seed", range(14))
+def test_randomised_scene_sweep(seed):
+    """Wider net than the hand-picked cases above: random array size, resolution, regime and device per seed;
+    kept states bit-exact, occupations / signal to 1e-6 wherever float64 resolves the spectrum."""
+    rng = np.random.default_rng(9000 + seed)
+    N = int(rng.integers(2, 9)); R = int(rng.choice([7, 10, 12, 16])); B = 2
+    mode = ["near", "mid", "start", "near"][seed % 4]
+    env = _env(B, N, R, seed=500 + seed)
+    env.reset()
+    st, steps = env.get_state()
+    for e in range(B):
+        st[e] = H.place(N, st[e], mode, rng)
+    env.set_state(st, steps)
+    from qadapt_hip import _lib
+    _lib.check(env._h, env._lib.qd_observe(env._h, None, 0, env._stream()), "qd_observe")
+    raw, _ = env.raw(); occ = env.occupations(); cand = env.candidates()
+    checked = 0
+    for e in range(B):
+        dev = H.dev_view(N, env._params_host[e]); sv = H.state_view(N, st[e])
+        for ch in range(N - 1):
+            ref = OC.csd_channel(dev, sv.vgm, dev.origin, sv.gate_v, sv.sensor_gt, sv.barrier_v, dev.window, ch, R)
+            assert np.array_equal(cand[e, ch], ref["states"]), (N, R, mode, e, ch)
+            ok = ref["tc"].max(axis=1) < 1e6
+            checked += int(ok.sum())
+            assert np.allclose(occ[e, ch][ok], ref["occ"][ok], rtol=1e-6, atol=1e-6), (N, R, mode, e, ch)
+            assert np.allclose(raw[e, ch][ok], ref["z"][ok], rtol=1e-6, atol=1e-9), (N, R, mode, e, ch)
+            # total charge of the ground state is an integer (hopping conserves it) wherever one sector wins clearly
+            if ok.sum() >= 8:
+                tot = occ[e, ch][ok].sum(axis=1)
+                assert np.mean(np.abs(tot - np.round(tot)) < 1e-6) > 0.9
+    assert checked > 0
+    env.close()
