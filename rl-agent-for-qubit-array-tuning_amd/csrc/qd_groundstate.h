@@ -353,6 +353,7 @@ __device__ void qd_ground_pixel(const QdPixelRec* __restrict__ rec, QdWaveLds& W
 #endif
         const double dk = (double)k;
         const bool huge_scale = __any(tscale > 1e30);
+        double sprev = 0.0;                                // previous Laguerre step (0: none yet)
         for (int it = 0; it < 48; ++it) {
             if (!__any(!conv)) break;
             // p, p', p'' at xl: three-term recurrences over the rows of T.  The first 8 rows use the
@@ -435,7 +436,15 @@ __device__ void qd_ground_pixel(const QdPixelRec* __restrict__ rec, QdWaveLds& W
                     const double xn = (den != 0.0) ? fma(-dk, qd_rcp(den), xl) : xl;
                     if (!(xn > xl)) conv = true;                       // monotone sequence has stalled
                     else {
-                        if (xn - xl <= 4e-16 * fmax(fabs(xn), fabs(xl))) conv = true;
+                        const double st = xn - xl, tol = 4e-16 * fmax(fabs(xn), fabs(xl));
+                        if (st <= tol) conv = true;
+                        // cubic convergence (simple lowest root): e_next ~ C st^3 with C ~ st / sprev^3, so the
+                        // iteration after this one would only confirm; stop when that prediction, with a factor
+                        // 100 in hand, is below the tolerance.  (Linear convergence towards a cluster, st ~ 0.4
+                        // sprev, never passes the test.)
+                        const double s2 = st * st, p3 = sprev * sprev * sprev;
+                        if (100.0 * s2 * s2 <= tol * p3) conv = true;
+                        sprev = st;
                         xl = xn;
                     }
                 }
