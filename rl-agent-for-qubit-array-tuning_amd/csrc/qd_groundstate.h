@@ -88,10 +88,12 @@ __device__ __forceinline__ double qd_half_sum(double v) {
     for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 32);
     return v;
 }
+// wave-wide maximum, returned through readfirstlane so that the compiler knows it is uniform: loop bounds
+// and slot guards built from it become scalar branches instead of exec-mask juggling
 __device__ __forceinline__ int qd_wave_max_int(int v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
-    return v;
+    return __builtin_amdgcn_readfirstlane(v);
 }
 
 // per-component (segment) reductions through the LDS publish buffer.  `seg` is
