@@ -193,8 +193,9 @@ __device__ void qd_ground_pixel(const QdPixelRec* __restrict__ rec, QdWaveLds& W
         const unsigned Z = ((cj | 0x88888888u) - ecode) ^ 0x88888888u;
         const int tz = __builtin_ctz(Z | 0x80000000u);     // Z == 0 (same state): tz = 31, Zs = 0, no hop (a nibble of Z is never 8)
         const unsigned Zs = Z >> tz;
-        const bool hop = (Zs == 0x1Fu || Zs == 0xF1u) && ((tcq >> tz) & 1u);
-        if (hop) nbrmask |= 1u << j;
+        // branch-free on purpose (bitwise, not short-circuit): the compiler otherwise builds a divergent branch per j
+        const unsigned hop = ((unsigned)(Zs == 0x1Fu) | (unsigned)(Zs == 0xF1u)) & (tcq >> tz) & 1u;
+        nbrmask |= hop << j;
     }
     // states beyond the valid count (|0..0> padding) neither hop nor are hopped to
     nbrmask = valid ? (nbrmask & (nvalid >= 32 ? 0xFFFFFFFFu : ((1u << nvalid) - 1u))) : 0u;
