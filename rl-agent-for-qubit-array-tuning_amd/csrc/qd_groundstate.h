@@ -466,14 +466,15 @@ __device__ void qd_ground_pixel(const QdPixelRec* __restrict__ rec, QdWaveLds& W
     {
         const double sig = lo;
         const double tiny = 1e-300 + 1e-18 * fmax(fabs(lo), fabs(hi));
-        double d = 1.0, bprev = 0.0;
+        double d = 1.0, bprev = 0.0, rdp = 1.0;
 #define QD_FAC_ROW(SLOT, FIRST)                                                     \
         {                                                                           \
             double di_ = al[SLOT] - sig;                                            \
-            if (!(FIRST)) { const double l_ = bprev * qd_rcp(d); di_ = di_ - l_ * bprev; W.lf[SLOT] = l_; } \
+            if (!(FIRST)) { const double l_ = bprev * rdp; di_ = di_ - l_ * bprev; W.lf[SLOT] = l_; } \
             if (!(di_ > tiny)) di_ = tiny;                                          \
             d = di_;                                                                \
-            W.rd[SLOT] = qd_rcp(d);                                                 \
+            rdp = qd_rcp(d);                                /* 1/d_i: stored, and reused as 1/d_{i-1} by the next row */ \
+            W.rd[SLOT] = rdp;                                                       \
             bprev = be[SLOT];                                                       \
         }
 #pragma unroll
@@ -522,7 +523,8 @@ __device__ void qd_ground_pixel(const QdPixelRec* __restrict__ rec, QdWaveLds& W
             for (int i = 7; i >= 0; --i) if (i < k) QD_BWD_ROW(MB.idx[i], i)
 #undef QD_BWD_ROW
             __builtin_amdgcn_wave_barrier();
-            const double inv = (nrm > 0.0) ? 1.0 / sqrt(nrm) : 1.0;
+            double inv = 1.0, sn_ = 0.0;
+            if (nrm > 0.0) qd_sqrt_rsqrt(nrm, sn_, inv);          // 1/sqrt by rsq + Newton (no correctly rounded norm needed)
 #pragma unroll
             for (int i = 0; i < 8; ++i) if (i < k) W.yv[MB.idx[i]] = W.yv[MB.idx[i]] * inv;
             {
@@ -570,7 +572,9 @@ __device__ void qd_ground_pixel(const QdPixelRec* __restrict__ rec, QdWaveLds& W
     }
     if (solve) {
         const double nx = qd_seg_sum(x * x, MB, buf, hb);
-        x = x * (1.0 / sqrt(nx));
+        double snx = 0.0, inx = 1.0;
+        if (nx > 0.0) qd_sqrt_rsqrt(nx, snx, inx);
+        x = x * inx;
     }
 
     // ---- 8. pick the lowest component, expectation occupations --------------
