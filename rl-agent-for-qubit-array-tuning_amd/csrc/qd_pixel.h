@@ -213,7 +213,8 @@ struct QdSearch {
 // final list when the caller wants the reference order.
 template <int N>
 QD_HD bool qd_lex_less(double ea, unsigned ia, double eb, unsigned ib) {
-    return ea < eb || (ea == eb && ia < ib);
+    // bitwise on purpose: short-circuit operators become divergent branches in the leaf loop
+    return (bool)((int)(ea < eb) | ((int)(ea == eb) & (int)(ia < ib)));
 }
 
 template <int N>
@@ -343,7 +344,7 @@ struct QdLevel {
             QdLevel<N, L + 1>::run(S, pn);
             const bool can_lo = lo >= kmin, can_hi = hi <= 3;
             if (!can_lo && !can_hi) return;
-            const bool take_lo = can_lo && (!can_hi || (kstar - (double)lo) <= ((double)hi - kstar));
+            const bool take_lo = (bool)((int)can_lo & ((int)!can_hi | (int)((kstar - (double)lo) <= ((double)hi - kstar))));
             k = take_lo ? lo : hi;
             lo -= take_lo ? 1 : 0;
             hi += take_lo ? 0 : 1;
