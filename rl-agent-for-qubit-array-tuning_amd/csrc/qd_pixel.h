@@ -358,12 +358,23 @@ struct QdLevel<N, N> {
 #ifndef __HIP_DEVICE_COMPILE__
         S.leaves++;
 #endif
+        // fetch every matrix entry the leaf needs before the arithmetic starts (on the GPU they are scalar
+        // loads: issued back to back they overlap, interleaved with the FMAs each one is waited for separately)
+        constexpr int J0 = QdSplit<N>::B + 1, NJ = N - J0;
+        double a[N][NJ > 0 ? NJ : 1];
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) a[i][j] = S.A[i * S.lda + J0 + j];
+#if defined(__HIP_DEVICE_COMPILE__)
+        __builtin_amdgcn_sched_barrier(0);
+#endif
         double E = 0.0;
 #pragma unroll
         for (int i = 0; i < N; ++i) {
             double t = (QdSplit<N>::B >= 0) ? S.pre2[i] : 0.0;
 #pragma unroll
-            for (int j = QdSplit<N>::B + 1; j < N; ++j) t = fma(S.A[i * S.lda + j], S.dv[j], t);
+            for (int j = 0; j < NJ; ++j) t = fma(a[i][j], S.dv[J0 + j], t);
             E = fma(S.dv[i], t, E);
         }
         qd_search_insert(S, E, S.idx);
