@@ -284,7 +284,8 @@ __device__ void qd_ground_pixel(const QdPixelRec* __restrict__ rec, QdWaveLds& W
 #else
     const bool solve = active && ssz > 1;
 #endif
-    const double q0 = solve ? 1.0 / sqrt((double)ssz) : 0.0;
+    double q0 = 0.0;
+    { double s_, r_; qd_sqrt_rsqrt((double)ssz, s_, r_); q0 = solve ? r_ : 0.0; }     // 1/sqrt(size), ssz >= 1
     double q = q0, qp = 0.0, bp = 0.0, anorm = 0.0;
     double al_mine = F, be_mine = 0.0, ib_mine = 0.0;      // singleton: T = [F]
     int k = solve ? 0 : 1;

@@ -343,7 +343,7 @@ struct QdLevel {
             }
             QdLevel<N, L + 1>::run(S, pn);
             const bool can_lo = lo >= kmin, can_hi = hi <= 3;
-            if (!can_lo && !can_hi) return;
+            if (!((int)can_lo | (int)can_hi)) return;
             const bool take_lo = (bool)((int)can_lo & ((int)!can_hi | (int)((kstar - (double)lo) <= ((double)hi - kstar))));
             k = take_lo ? lo : hi;
             lo -= take_lo ? 1 : 0;
