@@ -68,7 +68,27 @@ typedef struct qd_config {
     double kalman_process_noise;  /* capacitance_model.process_noise               */
     uint64_t rng_seed;            /* Philox key for the stochastic stages          */
     int64_t env_id_offset;        /* global id of env 0 (multi-GPU shards)         */
+    /* config variants reachable from env_config.yaml (env.py:393-441, 553-563, 592-618, 861-876) */
+    int32_t use_deltas;           /* simulator.use_deltas: gate actions are increments (env.py:864-867) */
+    int32_t sparse_reward;        /* reward.sparse_reward (env.py:393-414)         */
+    int32_t gate_curve_type;      /* QD_CURVE_* (reward.gate_curve_type, env.py:430-441) */
+    int32_t update_method;        /* QD_UPDATE_KALMAN / QD_UPDATE_DIRECT (KalmanUpdater.py / DirectUpdater.py) */
+    int32_t cnn_outputs;          /* 3: [NN, NNN_right, NNN_left]; 2: legacy nearest_neighbour [RL, LR] (env.py:592-618) */
+    int32_t reserved0;
+    double delta_max;             /* simulator.delta_max                           */
+    double gate_curve_exponent;   /* reward.gate_curve_exponent                    */
+    double plunger_radius;        /* reward.plunger_radius        (sparse)         */
+    double outer_plunger_radius;  /* reward.outer_plunger_radius  (sparse)         */
+    double outer_plunger_reward_max; /* reward.outer_plunger_reward_max (sparse)  */
+    double barrier_radius;        /* reward.barrier_radius        (sparse)         */
 } qd_config;
+
+#define QD_CURVE_CONSTANT 0
+#define QD_CURVE_POLYNOMIAL 1
+#define QD_CURVE_EXPONENTIAL 2
+#define QD_CURVE_LINEAR 3
+#define QD_UPDATE_KALMAN 0
+#define QD_UPDATE_DIRECT 1
 
 /* Sizes (in float64 elements) of the per-env parameter and state blocks whose
  * layout is documented in csrc/qd_common.h (mirrored by qadapt_hip/layout.py). */
@@ -137,6 +157,14 @@ int qd_set_state(qd_handle* h, const double* state_host, const int32_t* steps_ho
 int qd_get_raw(qd_handle* h, double* raw_host, double* plohi_host);
 int qd_get_occupations(qd_handle* h, double* occ_host);
 int qd_get_candidates(qd_handle* h, int32_t* states_host);
+/* eig_host [B][C][P][2] float64 (QD_FLAG_VALIDATE): per pixel the ground energy of the 32-state
+ * Hamiltonian (what jnp.linalg.eigh returns first, ground_state.py:150) and the relative residual
+ * ||H x - lambda x||_2 / ||H||_inf of the eigenpair the occupations were formed from. */
+int qd_get_eigen(qd_handle* h, double* eig_host);
+/* Checkpointing of the stochastic stages (SURVEY 5 "expose RNG seeds/counters"): the Philox
+ * counter word that numbers the observations rendered so far by this handle. */
+int qd_get_rng_state(const qd_handle* h, uint64_t* obs_serial);
+int qd_set_rng_state(qd_handle* h, uint64_t obs_serial);
 
 /* Timing hook for bench.py: runs `iters` back-to-back launches of the dominant
  * kernel (ground state) on the current data and returns the mean duration in

@@ -437,22 +437,45 @@ class KalmanOracle:
     def update_from_scan(self, left, outs):
         i = left
         var = lambda lv: float(np.exp(np.clip(lv, self.lb[0], self.lb[1])))
-        self._update(i, i + 1, outs[0][0], var(outs[0][1]))
-        if i + 2 < self.n:
-            self._update(i, i + 2, outs[1][0], var(outs[1][1]))
-        if i - 1 >= 0:
-            self._update(i + 1, i - 1, outs[2][0], var(outs[2][1]))
+        if self.include_nnn and len(outs) == 3:                       # KalmanUpdater.py:159-181
+            self._update(i, i + 1, outs[0][0], var(outs[0][1]))
+            if i + 2 < self.n:
+                self._update(i, i + 2, outs[1][0], var(outs[1][1]))
+            if i - 1 >= 0:
+                self._update(i + 1, i - 1, outs[2][0], var(outs[2][1]))
+        elif len(outs) == 2:                                          # :183-205 legacy [RL, LR]
+            self._update(i + 1, i, outs[0][0], var(outs[0][1]))
+            self._update(i, i + 1, outs[1][0], var(outs[1][1]))
+        else:
+            raise ValueError(f"Expected 2 or 3 outputs, got {len(outs)}")
 
     def update_from_cnn(self, values, log_vars):
-        """env.py:608-618: per channel i, the three CNN outputs NEGATED."""
+        """env.py:592-618: per channel i, the CNN outputs NEGATED (3 outputs, or 2 in the legacy
+        nearest_neighbour mode)."""
+        K = np.asarray(values).shape[-1]
         for i in range(self.n - 1):
             self.update_from_scan(i, [(-float(values[i, k]), float(log_vars[i, k]))
-                                      for k in range(3)])
+                                      for k in range(K)])
 
     def full_matrix(self):
         m = self.means.copy()
         np.fill_diagonal(m, 1.0)
         return m
+
+
+class DirectOracle(KalmanOracle):
+    """DirectUpdater.py:89-125: same interface and gating, but an accepted prediction REPLACES the state
+    (mean = clip(delta), variance = measurement variance).  Pinned to tests/golden/direct_traces.npz,
+    generated from the reference class itself."""
+
+    def _update(self, i, j, delta, R):
+        r, c = min(i, j), max(i, j)
+        if R > self.thr:
+            return False
+        nm = float(np.clip(delta, self.mb[0], self.mb[1]))
+        self.means[r, c] = self.means[c, r] = nm
+        self.vars[r, c] = self.vars[c, r] = R
+        return True
 
 
 # --------------------------------------------------------------------------
@@ -467,6 +490,11 @@ def vgm_from_estimate(dev: Device, cgd_estimate):
     gates_only = est[:, :dev.n_gate]
     vgm = -np.linalg.pinv(dev.cdd_inv_full @ gates_only)
     return -vgm                                   # charge_carrier == 'electrons' (:938-939)
+
+
+def perfect_vgm(dev: Device):
+    """qarray_base_class.py:879-901 (update_method "perfect", env.py:181-182), electrons sign applied."""
+    return np.linalg.pinv(dev.cdd_inv_full @ dev.cgd_full[:, :dev.n_gate])
 
 
 def identity_vgm(n_dot):
@@ -504,20 +532,54 @@ def rescale(action, lo, hi):
     return a * (hi - lo) + lo
 
 
+def rescale_gate_deltas(action, current, lo, hi, delta_max):
+    """env.py:861-870 with use_deltas: the increment stays float32 (float32 array times Python floats), the
+    in-place `obs += current` stores the float64 sum back as float32, np.clip against the float64 range
+    widens the result."""
+    obs = np.clip(np.array(action).flatten().astype(np.float32), -1, 1)
+    obs = (obs + 1) / 2
+    dmax, dmin = delta_max, -delta_max
+    obs = obs * (dmax - dmin) + dmin
+    assert obs.dtype == np.float32
+    obs += np.asarray(current, dtype=np.float64)
+    return np.clip(obs, lo, hi)
+
+
 def reward(dev: Device, gate_gt, barrier_gt, gate_v, barrier_v,
-           gate_ramp_start=40.0, gate_quadratic_start=1.0, barrier_ramp_start=6.0):
-    """Non-sparse reward with gate_curve_type 'constant' (env_config.yaml)."""
+           gate_ramp_start=40.0, gate_quadratic_start=1.0, barrier_ramp_start=6.0,
+           gate_curve_type="constant", gate_curve_exponent=2.0, sparse_reward=False,
+           plunger_radius=2, outer_plunger_radius=10, outer_plunger_reward_max=0.5, barrier_radius=2):
+    """env.py:350-462 (defaults = env_config.yaml)."""
     N = dev.n_dot
     gd = np.abs(gate_gt - gate_v) * np.abs([dev.cgd_full[i, i] for i in range(N)])
     bd = np.abs(barrier_gt - barrier_v) * dev.alpha
+    if sparse_reward:                                                 # :393-414
+        gr = np.zeros_like(gd)
+        gr[gd <= plunger_radius] = 1.0
+        outer = (gd > plunger_radius) & (gd <= outer_plunger_radius)
+        if np.any(outer):
+            nd = (gd[outer] - plunger_radius) / (outer_plunger_radius - plunger_radius)
+            gr[outer] = outer_plunger_reward_max * (1.0 - nd)
+        return gr, np.where(bd <= barrier_radius, 1.0, 0.0)
     gr = np.zeros_like(gd)
     for i, d in enumerate(gd):
         if d >= gate_ramp_start:
             gr[i] = 0.0
         elif d > gate_quadratic_start:
-            gr[i] = 0.5 * (gate_ramp_start - d) / (gate_ramp_start - gate_quadratic_start)
+            gr[i] = 0.5 * ((gate_ramp_start - d) / (gate_ramp_start - gate_quadratic_start))
         else:
-            gr[i] = 0.5 + 0.5 * 1
+            nrm = (gate_quadratic_start - d) / gate_quadratic_start
+            if gate_curve_type == "polynomial":
+                cv = nrm ** gate_curve_exponent
+            elif gate_curve_type == "constant":
+                cv = 1
+            elif gate_curve_type == "exponential":
+                cv = (np.exp(gate_curve_exponent * nrm) - 1) / (np.exp(gate_curve_exponent) - 1)
+            elif gate_curve_type == "linear":
+                cv = nrm
+            else:
+                raise ValueError(f"Unknown curve type: {gate_curve_type}")
+            gr[i] = 0.5 + 0.5 * cv
     br = np.zeros_like(bd)
     for i, d in enumerate(bd):
         br[i] = 0.0 if d >= barrier_ramp_start else (barrier_ramp_start - d) / barrier_ramp_start
@@ -677,11 +739,15 @@ class OracleEnv:
     replaced by caller-supplied (values, log_vars) of shape (C,3) (row f1 of
     SURVEY §8 is out of scope; env.py:568-581 is an input provider here)."""
 
-    def __init__(self, n_dot, resolution, max_steps=50):
+    def __init__(self, n_dot, resolution, max_steps=50, update_method="kalman", nearest_neighbour=False,
+                 use_deltas=False, delta_max=5.0, reward_cfg=None):
         self.N = n_dot; self.R = resolution; self.max_steps = max_steps
+        self.update_method = update_method; self.use_deltas = use_deltas; self.delta_max = delta_max
+        self.reward_cfg = dict(reward_cfg or {})
         # QUIRK kept: the Kalman filter is built once in __init__ (env.py:130,
         # 779-787) and is NOT reset by reset(); it survives episodes.
-        self.kalman = KalmanOracle(n_dot)
+        cls = DirectOracle if update_method == "direct" else KalmanOracle       # env.py:773-787
+        self.kalman = cls(n_dot, include_nnn=not nearest_neighbour)
 
     def reset(self, sample, cnn_values, cnn_log_vars):
         s = sample; N = self.N
@@ -689,6 +755,8 @@ class OracleEnv:
         self.window = s["window_delta"]
         self.dev = device_from_sample(s)
         self.vgm = identity_vgm(N)                                   # env.py:179
+        if self.update_method == "perfect":                          # env.py:181-182
+            self.vgm = perfect_vgm(self.dev)
         self.origin = np.concatenate([s["offset"], [0.0]])           # env.py:193
         pgt, bgt, sgt = ground_truth(self.dev, self.vgm, self.origin)
         # env.py:808-839 (np.random.uniform(low, high) == low + (high-low)*u)
@@ -715,21 +783,27 @@ class OracleEnv:
         raw = get_obs_images(self.dev, self.vgm, self.origin, self.gate_v, self.barrier_v,
                              self.sensor_gt, self.window, self.R)
         self.raw_image = raw
+        self.vgm_at_obs = np.array(self.vgm, copy=True)              # (tests: the VGM this image was rendered with)
         return {"image": normalise_image(raw),
                 "obs_gate_voltages": normalise_voltages(self.gate_v, self.plunger_min, self.plunger_max),
                 "obs_barrier_voltages": normalise_voltages(self.barrier_v, self.barrier_min, self.barrier_max)}
 
     def _kalman_and_vgm(self, values, log_vars):
+        if self.update_method in (None, "perfect"):                  # env.py:549-554
+            return
         self.kalman.update_from_cnn(np.asarray(values), np.asarray(log_vars))
         self.vgm = vgm_from_estimate(self.dev, self.kalman.full_matrix())
 
     def step(self, gate_action, barrier_action, cnn_values, cnn_log_vars):
         self.step_count += 1
-        self.gate_v = rescale(gate_action, self.plunger_min, self.plunger_max)
+        if self.use_deltas:
+            self.gate_v = rescale_gate_deltas(gate_action, self.gate_v, self.plunger_min, self.plunger_max, self.delta_max)
+        else:
+            self.gate_v = rescale(gate_action, self.plunger_min, self.plunger_max)
         self.barrier_v = rescale(barrier_action, self.barrier_min, self.barrier_max)
         # QUIRK kept: reward is against the ground truth of the PREVIOUS step
         # (env.py:279 runs before :298).
-        rew = reward(self.dev, self.gate_gt, self.barrier_gt, self.gate_v, self.barrier_v)
+        rew = reward(self.dev, self.gate_gt, self.barrier_gt, self.gate_v, self.barrier_v, **self.reward_cfg)
         truncated = self.step_count >= self.max_steps
         obs = self._observe()
         self._kalman_and_vgm(cnn_values, cnn_log_vars)

@@ -15,7 +15,7 @@ struct qd_handle {
     QdLayout L;
     int N, R, B, C, P;
     int chunk;
-    double *params, *state, *zraw, *plohi, *occ;
+    double *params, *state, *zraw, *plohi, *occ, *eig;
     int* steps;
     QdPixelRec* recs;
     size_t recs_envs;                       // envs the recs buffer holds
@@ -34,6 +34,31 @@ static int qd_fail(qd_handle* h, int code, const char* what, hipError_t e = hipS
 }
 #define QD_HIP(call)                                                              \
     do { hipError_t e_ = (call); if (e_ != hipSuccess) return qd_fail(h, QD_ERR_HIP, #call, e_); } while (0)
+
+// Every entry point works on the handle's GPU and leaves the calling thread's current device
+// (which is also PyTorch's) as it found it.
+struct QdDeviceGuard {
+    int prev; bool switched; hipError_t err;
+    explicit QdDeviceGuard(int dev) : prev(-1), switched(false), err(hipSuccess) {
+        err = hipGetDevice(&prev);
+        if (err == hipSuccess && prev != dev) { err = hipSetDevice(dev); switched = (err == hipSuccess); }
+    }
+    ~QdDeviceGuard() { if (switched) (void)hipSetDevice(prev); }
+};
+#define QD_ON_DEVICE(h)                                                           \
+    QdDeviceGuard guard_((h)->device);                                            \
+    if (guard_.err != hipSuccess) return qd_fail((h), QD_ERR_HIP, "hipSetDevice", guard_.err)
+
+// two events that are destroyed on every exit path
+struct QdEventPair {
+    hipEvent_t a, b; bool ok;
+    QdEventPair() : a(nullptr), b(nullptr), ok(false) {
+        if (hipEventCreate(&a) != hipSuccess) { a = nullptr; return; }
+        if (hipEventCreate(&b) != hipSuccess) { b = nullptr; return; }
+        ok = true;
+    }
+    ~QdEventPair() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
+};
 
 #define QD_DISPATCH_N(N_, ...)                                                    \
     switch (N_) {                                                                 \
@@ -56,11 +81,28 @@ extern "C" int qd_layout_query(int n, int32_t* out) {
     return QD_OK;
 }
 
+// Kalman priors (KalmanUpdater.py:64-81): NN couplings prior_mean, NNN couplings prior_mean_nnn when they are
+// tracked (include_nnn = not nearest_neighbour, env.py:784), variance prior_variance; everything else 0.
+static void qd_kalman_priors(const qd_config& cfg, int N, double* km, double* kv) {
+    for (int i = 0; i < N * N; ++i) { km[i] = 0.0; kv[i] = 0.0; }
+    for (int i = 0; i < N - 1; ++i) {
+        km[i * N + i + 1] = km[(i + 1) * N + i] = cfg.kalman_prior_mean;
+        kv[i * N + i + 1] = kv[(i + 1) * N + i] = cfg.kalman_prior_variance;
+    }
+    if (cfg.cnn_outputs != 2)
+        for (int i = 0; i < N - 2; ++i) {
+            km[i * N + i + 2] = km[(i + 2) * N + i] = cfg.kalman_prior_mean_nnn;
+            kv[i * N + i + 2] = kv[(i + 2) * N + i] = cfg.kalman_prior_variance;
+        }
+}
+
 extern "C" const char* qd_last_error(const qd_handle* h) { return h ? h->err : "null handle"; }
 
 extern "C" int qd_create(const qd_config* cfg, int device, qd_handle** out) {
     if (!cfg || !out || cfg->struct_size != (int32_t)sizeof(qd_config)) return QD_ERR_ARG;
     if (cfg->n_dot < 2 || cfg->n_dot > QD_MAXN || cfg->resolution < 2 || cfg->batch < 1) return QD_ERR_ARG;
+    if (cfg->cnn_outputs != 2 && cfg->cnn_outputs != 3) return QD_ERR_ARG;
+    if (cfg->gate_curve_type < 0 || cfg->gate_curve_type > 3 || cfg->update_method < 0 || cfg->update_method > 1) return QD_ERR_ARG;
     qd_handle* h = new (std::nothrow) qd_handle();
     if (!h) return QD_ERR_NOMEM;
     memset(h, 0, sizeof(*h));
@@ -68,7 +110,7 @@ extern "C" int qd_create(const qd_config* cfg, int device, qd_handle** out) {
     h->N = cfg->n_dot; h->R = cfg->resolution; h->B = cfg->batch;
     h->C = h->N - 1; h->P = h->R * h->R; h->L = qd_layout(h->N);
     *out = h;
-    QD_HIP(hipSetDevice(device));
+    QD_ON_DEVICE(h);
     const size_t per_env_rec = (size_t)h->C * h->P * sizeof(QdPixelRec);
     int chunk = cfg->env_chunk;
     if (cfg->flags & QD_FLAG_VALIDATE) chunk = h->B;
@@ -92,11 +134,15 @@ extern "C" int qd_create(const qd_config* cfg, int device, qd_handle** out) {
     }
     if ((cfg->flags & QD_FLAG_VALIDATE) || (cfg->noise_flags & QD_NOISE_LATCH))
         QD_HIP(hipMalloc(&h->occ, sizeof(double) * (size_t)h->B * h->C * h->P * h->N));
+    if (cfg->flags & QD_FLAG_VALIDATE) {
+        QD_HIP(hipMalloc(&h->eig, sizeof(double) * 2 * (size_t)h->B * h->C * h->P));
+        QD_HIP(hipMemset(h->eig, 0, sizeof(double) * 2 * (size_t)h->B * h->C * h->P));
+    }
     QD_HIP(hipMemset(h->params, 0, sizeof(double) * (size_t)h->B * h->L.size));
     QD_HIP(hipMemset(h->steps, 0, sizeof(int) * (size_t)h->B));
     QD_HIP(hipMemset(h->zraw, 0, sizeof(double) * (size_t)h->B * h->C * h->P));
     QD_HIP(hipMemset(h->plohi, 0, sizeof(double) * 2 * (size_t)h->B));
-    // Kalman priors (KalmanUpdater.py:64-81) into every env's state block
+    // Kalman priors into every env's state block
     {
         const int N = h->N;
         double* host = (double*)calloc((size_t)h->B * h->L.s_size, sizeof(double));
@@ -104,14 +150,7 @@ extern "C" int qd_create(const qd_config* cfg, int device, qd_handle** out) {
         for (int e = 0; e < h->B; ++e) {
             double* st = host + (size_t)e * h->L.s_size;
             for (int i = 0; i < N + 1; ++i) st[h->L.s_vgm + i * (N + 1) + i] = -1.0;
-            for (int i = 0; i < N - 1; ++i) {
-                st[h->L.s_kmean + i * N + i + 1] = st[h->L.s_kmean + (i + 1) * N + i] = cfg->kalman_prior_mean;
-                st[h->L.s_kvar + i * N + i + 1] = st[h->L.s_kvar + (i + 1) * N + i] = cfg->kalman_prior_variance;
-            }
-            for (int i = 0; i < N - 2; ++i) {
-                st[h->L.s_kmean + i * N + i + 2] = st[h->L.s_kmean + (i + 2) * N + i] = cfg->kalman_prior_mean_nnn;
-                st[h->L.s_kvar + i * N + i + 2] = st[h->L.s_kvar + (i + 2) * N + i] = cfg->kalman_prior_variance;
-            }
+            qd_kalman_priors(*cfg, N, st + h->L.s_kmean, st + h->L.s_kvar);
         }
         hipError_t e_ = hipMemcpy(h->state, host, sizeof(double) * (size_t)h->B * h->L.s_size, hipMemcpyHostToDevice);
         free(host);
@@ -123,8 +162,8 @@ extern "C" int qd_create(const qd_config* cfg, int device, qd_handle** out) {
 
 extern "C" int qd_destroy(qd_handle* h) {
     if (!h) return QD_ERR_ARG;
-    (void)hipSetDevice(h->device);
-    void* bufs[] = {h->params, h->state, h->steps, h->zraw, h->plohi, h->recs, h->occ, h->tel};
+    QdDeviceGuard guard_(h->device);
+    void* bufs[] = {h->params, h->state, h->steps, h->zraw, h->plohi, h->recs, h->occ, h->tel, h->eig};
     for (void* b : bufs) if (b) (void)hipFree(b);
     delete h;
     return QD_OK;
@@ -140,57 +179,65 @@ extern "C" int qd_load_episodes(qd_handle* h, const int32_t* env_ids, int n, con
                                 const double* state, int reset_kalman, void* stream) {
     if (!h || !env_ids || n < 0 || !params || !state) return qd_fail(h, QD_ERR_ARG, "qd_load_episodes: bad argument");
     hipStream_t s = (hipStream_t)stream;
-    QD_HIP(hipSetDevice(h->device));
+    QD_ON_DEVICE(h);
     const QdLayout& L = h->L;
     const int N = h->N;
     const size_t pre = (size_t)L.s_kmean;                        // everything before the Kalman block
-    bool contiguous = n > 1 && !reset_kalman;
+    if (n == 0) return QD_OK;
+    for (int k = 0; k < n; ++k)
+        if (env_ids[k] < 0 || env_ids[k] >= h->B) return qd_fail(h, QD_ERR_ARG, "qd_load_episodes: env id out of range");
+    bool contiguous = true;
     for (int k = 1; k < n && contiguous; ++k) contiguous = env_ids[k] == env_ids[0] + k;
+    // the state rows uploaded are the first `pre` doubles, or the whole row with fresh Kalman priors
+    double* staged = nullptr;
+    const double* src = state; size_t width = pre;
+    if (reset_kalman) {
+        staged = (double*)malloc(sizeof(double) * (size_t)n * L.s_size);
+        if (!staged) return qd_fail(h, QD_ERR_NOMEM, "malloc");
+        double km[QD_MAXN * QD_MAXN], kv[QD_MAXN * QD_MAXN];
+        qd_kalman_priors(h->cfg, N, km, kv);
+        for (int k = 0; k < n; ++k) {
+            double* row = staged + (size_t)k * L.s_size;
+            memcpy(row, state + (size_t)k * L.s_size, sizeof(double) * L.s_size);
+            memcpy(row + L.s_kmean, km, sizeof(double) * N * N);
+            memcpy(row + L.s_kvar, kv, sizeof(double) * N * N);
+        }
+        src = staged; width = (size_t)L.s_kvar + (size_t)N * N;
+    }
+    hipError_t er = hipSuccess;
     if (contiguous) {
         const int e0 = env_ids[0];
-        if (e0 < 0 || e0 + n > h->B) return qd_fail(h, QD_ERR_ARG, "qd_load_episodes: env id out of range");
-        QD_HIP(hipMemcpyAsync(h->params + (size_t)e0 * L.size, params, sizeof(double) * L.size * n,
-                              hipMemcpyHostToDevice, s));
-        QD_HIP(hipMemcpy2DAsync(h->state + (size_t)e0 * L.s_size, sizeof(double) * L.s_size, state,
-                                sizeof(double) * L.s_size, sizeof(double) * pre, n, hipMemcpyHostToDevice, s));
-        QD_HIP(hipMemsetAsync(h->steps + e0, 0, sizeof(int) * n, s));
-        QD_HIP(hipStreamSynchronize(s));
-        return QD_OK;
-    }
-    for (int k = 0; k < n; ++k) {
-        const int e = env_ids[k];
-        if (e < 0 || e >= h->B) return qd_fail(h, QD_ERR_ARG, "qd_load_episodes: env id out of range");
-        QD_HIP(hipMemcpyAsync(h->params + (size_t)e * L.size, params + (size_t)k * L.size,
-                              sizeof(double) * L.size, hipMemcpyHostToDevice, s));
-        QD_HIP(hipMemcpyAsync(h->state + (size_t)e * L.s_size, state + (size_t)k * L.s_size,
-                              sizeof(double) * pre, hipMemcpyHostToDevice, s));
-        if (reset_kalman) {
-            double kal[2 * QD_MAXN * QD_MAXN];
-            memset(kal, 0, sizeof(kal));
-            double* km = kal; double* kv = kal + N * N;
-            for (int i = 0; i < N - 1; ++i) {
-                km[i * N + i + 1] = km[(i + 1) * N + i] = h->cfg.kalman_prior_mean;
-                kv[i * N + i + 1] = kv[(i + 1) * N + i] = h->cfg.kalman_prior_variance;
-            }
-            for (int i = 0; i < N - 2; ++i) {
-                km[i * N + i + 2] = km[(i + 2) * N + i] = h->cfg.kalman_prior_mean_nnn;
-                kv[i * N + i + 2] = kv[(i + 2) * N + i] = h->cfg.kalman_prior_variance;
-            }
-            QD_HIP(hipMemcpy(h->state + (size_t)e * L.s_size + L.s_kmean, kal, sizeof(double) * 2 * N * N,
-                             hipMemcpyHostToDevice));
+        er = hipMemcpyAsync(h->params + (size_t)e0 * L.size, params, sizeof(double) * L.size * n, hipMemcpyHostToDevice, s);
+        if (er == hipSuccess)
+            er = hipMemcpy2DAsync(h->state + (size_t)e0 * L.s_size, sizeof(double) * L.s_size, src,
+                                  sizeof(double) * L.s_size, sizeof(double) * width, n, hipMemcpyHostToDevice, s);
+        if (er == hipSuccess) er = hipMemsetAsync(h->steps + e0, 0, sizeof(int) * n, s);
+    } else {
+        for (int k = 0; k < n && er == hipSuccess; ++k) {
+            const int e = env_ids[k];
+            er = hipMemcpyAsync(h->params + (size_t)e * L.size, params + (size_t)k * L.size,
+                                sizeof(double) * L.size, hipMemcpyHostToDevice, s);
+            if (er == hipSuccess)
+                er = hipMemcpyAsync(h->state + (size_t)e * L.s_size, src + (size_t)k * L.s_size,
+                                    sizeof(double) * width, hipMemcpyHostToDevice, s);
+            if (er == hipSuccess) er = hipMemsetAsync(h->steps + e, 0, sizeof(int), s);
         }
-        QD_HIP(hipMemsetAsync(h->steps + e, 0, sizeof(int), s));
     }
     // pageable host memory: make sure the copies have consumed the caller's buffers
-    QD_HIP(hipStreamSynchronize(s));
+    if (er == hipSuccess) er = hipStreamSynchronize(s);
+    free(staged);
+    if (er != hipSuccess) return qd_fail(h, QD_ERR_HIP, "qd_load_episodes: copy", er);
     return QD_OK;
 }
 
 extern "C" int qd_apply_actions(qd_handle* h, const float* actions, double* rewards, uint8_t* truncated, void* stream) {
     if (!h || !actions) return qd_fail(h, QD_ERR_ARG, "qd_apply_actions: bad argument");
     hipStream_t s = (hipStream_t)stream;
-    QD_HIP(hipSetDevice(h->device));
-    QdRewardCfg rc{h->cfg.gate_ramp_start, h->cfg.gate_quadratic_start, h->cfg.barrier_ramp_start, h->cfg.max_steps};
+    QD_ON_DEVICE(h);
+    const qd_config& c = h->cfg;
+    QdRewardCfg rc{c.gate_ramp_start, c.gate_quadratic_start, c.barrier_ramp_start, c.max_steps,
+                   c.use_deltas, c.sparse_reward, c.gate_curve_type, c.delta_max, c.gate_curve_exponent,
+                   c.plunger_radius, c.outer_plunger_radius, c.outer_plunger_reward_max, c.barrier_radius};
     const int blk = 64, grd = (h->B + blk - 1) / blk;
     QD_DISPATCH_N(h->N, qd_k_actions<NN><<<dim3(grd), dim3(blk), 0, s>>>(h->B, h->params,
                                             h->state, h->steps, actions, rewards, truncated, rc));
@@ -215,8 +262,13 @@ static QdNoiseCfg qd_noise_cfg(const qd_handle* h) {
 
 static int qd_launch_ground(qd_handle* h, const int32_t* env_ids, int base, int cnt, hipStream_t s) {
     dim3 g2((h->P + QD_GS_PPB - 1) / QD_GS_PPB, h->C, cnt);
-    QD_DISPATCH_N(h->N, qd_k_ground<NN><<<g2, dim3(QD_GS_BLOCK), 0, s>>>(env_ids, base, h->R,
-                                            h->params, h->recs, h->zraw, h->occ, h->state, h->cfg.noise_flags));
+    if (h->eig) {
+        QD_DISPATCH_N(h->N, qd_k_ground<NN, true><<<g2, dim3(QD_GS_BLOCK), 0, s>>>(env_ids, base, h->R,
+                                                h->params, h->recs, h->zraw, h->occ, h->state, h->cfg.noise_flags, h->eig));
+    } else {
+        QD_DISPATCH_N(h->N, qd_k_ground<NN, false><<<g2, dim3(QD_GS_BLOCK), 0, s>>>(env_ids, base, h->R,
+                                                h->params, h->recs, h->zraw, h->occ, h->state, h->cfg.noise_flags, nullptr));
+    }
     QD_HIP(hipGetLastError());
     return QD_OK;
 }
@@ -224,7 +276,7 @@ static int qd_launch_ground(qd_handle* h, const int32_t* env_ids, int base, int 
 extern "C" int qd_observe(qd_handle* h, const int32_t* env_ids, int n, void* stream) {
     if (!h || n < 0) return qd_fail(h, QD_ERR_ARG, "qd_observe: bad argument");
     hipStream_t s = (hipStream_t)stream;
-    QD_HIP(hipSetDevice(h->device));
+    QD_ON_DEVICE(h);
     if (!env_ids) n = h->B;
     if (n == 0) return QD_OK;
     if (n > h->B) return qd_fail(h, QD_ERR_ARG, "qd_observe: n > batch");
@@ -269,10 +321,11 @@ extern "C" int qd_update_capacitance(qd_handle* h, const int32_t* env_ids, int n
                                      const float* log_vars, int recompute_gt, void* stream) {
     if (!h || n < 0) return qd_fail(h, QD_ERR_ARG, "qd_update_capacitance: bad argument");
     hipStream_t s = (hipStream_t)stream;
-    QD_HIP(hipSetDevice(h->device));
+    QD_ON_DEVICE(h);
     if (!env_ids) n = h->B;
     if (n == 0) return QD_OK;
-    QdKalmanCfg kc{h->cfg.kalman_variance_threshold, h->cfg.kalman_process_noise};
+    QdKalmanCfg kc{h->cfg.kalman_variance_threshold, h->cfg.kalman_process_noise, h->cfg.update_method == QD_UPDATE_DIRECT ? 1 : 0,
+                   h->cfg.cnn_outputs};
     const int blk = 64, grd = (n + blk - 1) / blk;
     QD_DISPATCH_N(h->N, qd_k_update<NN><<<dim3(grd), dim3(blk), 0, s>>>(env_ids, n, h->params,
                                             h->state, values, log_vars, recompute_gt, kc));
@@ -291,7 +344,7 @@ extern "C" int qd_step(qd_handle* h, const float* actions, const float* values, 
 
 extern "C" int qd_get_state(qd_handle* h, double* state, int32_t* steps) {
     if (!h) return QD_ERR_ARG;
-    QD_HIP(hipSetDevice(h->device));
+    QD_ON_DEVICE(h);
     QD_HIP(hipDeviceSynchronize());
     if (state) QD_HIP(hipMemcpy(state, h->state, sizeof(double) * (size_t)h->B * h->L.s_size, hipMemcpyDeviceToHost));
     if (steps) QD_HIP(hipMemcpy(steps, h->steps, sizeof(int) * (size_t)h->B, hipMemcpyDeviceToHost));
@@ -299,7 +352,7 @@ extern "C" int qd_get_state(qd_handle* h, double* state, int32_t* steps) {
 }
 extern "C" int qd_set_state(qd_handle* h, const double* state, const int32_t* steps) {
     if (!h) return QD_ERR_ARG;
-    QD_HIP(hipSetDevice(h->device));
+    QD_ON_DEVICE(h);
     QD_HIP(hipDeviceSynchronize());
     if (state) QD_HIP(hipMemcpy(h->state, state, sizeof(double) * (size_t)h->B * h->L.s_size, hipMemcpyHostToDevice));
     if (steps) QD_HIP(hipMemcpy(h->steps, steps, sizeof(int) * (size_t)h->B, hipMemcpyHostToDevice));
@@ -307,7 +360,7 @@ extern "C" int qd_set_state(qd_handle* h, const double* state, const int32_t* st
 }
 extern "C" int qd_get_raw(qd_handle* h, double* raw, double* plohi) {
     if (!h) return QD_ERR_ARG;
-    QD_HIP(hipSetDevice(h->device));
+    QD_ON_DEVICE(h);
     QD_HIP(hipDeviceSynchronize());
     if (raw) QD_HIP(hipMemcpy(raw, h->zraw, sizeof(double) * (size_t)h->B * h->C * h->P, hipMemcpyDeviceToHost));
     if (plohi) QD_HIP(hipMemcpy(plohi, h->plohi, sizeof(double) * 2 * (size_t)h->B, hipMemcpyDeviceToHost));
@@ -316,7 +369,7 @@ extern "C" int qd_get_raw(qd_handle* h, double* raw, double* plohi) {
 extern "C" int qd_get_occupations(qd_handle* h, double* occ) {
     if (!h || !occ) return QD_ERR_ARG;
     if (!h->occ) return qd_fail(h, QD_ERR_STATE, "qd_get_occupations needs QD_FLAG_VALIDATE");
-    QD_HIP(hipSetDevice(h->device));
+    QD_ON_DEVICE(h);
     QD_HIP(hipDeviceSynchronize());
     QD_HIP(hipMemcpy(occ, h->occ, sizeof(double) * (size_t)h->B * h->C * h->P * h->N, hipMemcpyDeviceToHost));
     return QD_OK;
@@ -324,39 +377,63 @@ extern "C" int qd_get_occupations(qd_handle* h, double* occ) {
 extern "C" int qd_get_candidates(qd_handle* h, int32_t* states) {
     if (!h || !states) return QD_ERR_ARG;
     if (!(h->cfg.flags & QD_FLAG_VALIDATE)) return qd_fail(h, QD_ERR_STATE, "qd_get_candidates needs QD_FLAG_VALIDATE");
-    QD_HIP(hipSetDevice(h->device));
+    QD_ON_DEVICE(h);
     QD_HIP(hipDeviceSynchronize());
+    // records come over in bounded slices (64 MiB of host staging at most)
     const size_t nrec = (size_t)h->B * h->C * h->P;
-    QdPixelRec* host = (QdPixelRec*)malloc(nrec * sizeof(QdPixelRec));
+    const size_t slice = ((size_t)64 << 20) / sizeof(QdPixelRec);
+    QdPixelRec* host = (QdPixelRec*)malloc((nrec < slice ? nrec : slice) * sizeof(QdPixelRec));
     if (!host) return qd_fail(h, QD_ERR_NOMEM, "malloc");
-    hipError_t e_ = hipMemcpy(host, h->recs, nrec * sizeof(QdPixelRec), hipMemcpyDeviceToHost);
-    if (e_ != hipSuccess) { free(host); return qd_fail(h, QD_ERR_HIP, "hipMemcpy(recs)", e_); }
     static const int DELTA[4] = {-1, 0, 1, 2};
     const int N = h->N;
-    for (size_t r = 0; r < nrec; ++r)
-        for (int m = 0; m < QD_K; ++m)
-            for (int i = 0; i < N; ++i) {
-                const int dig = (host[r].idx[m] >> (2 * (N - 1 - i))) & 3;
-                states[(r * QD_K + m) * N + i] = m < host[r].nvalid ? host[r].fl[i] + DELTA[dig] : 0;
-            }
+    for (size_t r0 = 0; r0 < nrec; r0 += slice) {
+        const size_t cnt = nrec - r0 < slice ? nrec - r0 : slice;
+        hipError_t e_ = hipMemcpy(host, h->recs + r0, cnt * sizeof(QdPixelRec), hipMemcpyDeviceToHost);
+        if (e_ != hipSuccess) { free(host); return qd_fail(h, QD_ERR_HIP, "hipMemcpy(recs)", e_); }
+        for (size_t r = 0; r < cnt; ++r)
+            for (int m = 0; m < QD_K; ++m)
+                for (int i = 0; i < N; ++i) {
+                    const int dig = (host[r].idx[m] >> (2 * (N - 1 - i))) & 3;
+                    states[((r0 + r) * QD_K + m) * N + i] = m < host[r].nvalid ? host[r].fl[i] + DELTA[dig] : 0;
+                }
+    }
     free(host);
+    return QD_OK;
+}
+
+extern "C" int qd_get_eigen(qd_handle* h, double* eig) {
+    if (!h || !eig) return QD_ERR_ARG;
+    if (!h->eig) return qd_fail(h, QD_ERR_STATE, "qd_get_eigen needs QD_FLAG_VALIDATE");
+    QD_ON_DEVICE(h);
+    QD_HIP(hipDeviceSynchronize());
+    QD_HIP(hipMemcpy(eig, h->eig, sizeof(double) * 2 * (size_t)h->B * h->C * h->P, hipMemcpyDeviceToHost));
+    return QD_OK;
+}
+
+extern "C" int qd_get_rng_state(const qd_handle* h, uint64_t* obs_serial) {
+    if (!h || !obs_serial) return QD_ERR_ARG;
+    *obs_serial = h->obs_serial;
+    return QD_OK;
+}
+extern "C" int qd_set_rng_state(qd_handle* h, uint64_t obs_serial) {
+    if (!h) return QD_ERR_ARG;
+    h->obs_serial = obs_serial;
     return QD_OK;
 }
 
 extern "C" int qd_time_ground_kernel(qd_handle* h, int iters, float* mean_ms, void* stream) {
     if (!h || iters < 1 || !mean_ms) return QD_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
-    QD_HIP(hipSetDevice(h->device));
-    hipEvent_t a, b;
-    QD_HIP(hipEventCreate(&a)); QD_HIP(hipEventCreate(&b));
+    QD_ON_DEVICE(h);
+    QdEventPair ev;
+    if (!ev.ok) return qd_fail(h, QD_ERR_HIP, "hipEventCreate");
     const int cnt = h->chunk < h->B ? h->chunk : h->B;
-    QD_HIP(hipEventRecord(a, s));
+    QD_HIP(hipEventRecord(ev.a, s));
     for (int i = 0; i < iters; ++i) { int rc = qd_launch_ground(h, nullptr, 0, cnt, s); if (rc) return rc; }
-    QD_HIP(hipEventRecord(b, s));
-    QD_HIP(hipEventSynchronize(b));
+    QD_HIP(hipEventRecord(ev.b, s));
+    QD_HIP(hipEventSynchronize(ev.b));
     float ms = 0.f;
-    QD_HIP(hipEventElapsedTime(&ms, a, b));
-    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    QD_HIP(hipEventElapsedTime(&ms, ev.a, ev.b));
     *mean_ms = ms / iters;
     return QD_OK;
 }
@@ -364,22 +441,21 @@ extern "C" int qd_time_ground_kernel(qd_handle* h, int iters, float* mean_ms, vo
 extern "C" int qd_time_candidates_kernel(qd_handle* h, int iters, float* mean_ms, void* stream) {
     if (!h || iters < 1 || !mean_ms) return QD_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
-    QD_HIP(hipSetDevice(h->device));
-    hipEvent_t a, b;
-    QD_HIP(hipEventCreate(&a)); QD_HIP(hipEventCreate(&b));
+    QD_ON_DEVICE(h);
+    QdEventPair ev;
+    if (!ev.ok) return qd_fail(h, QD_ERR_HIP, "hipEventCreate");
     const int cnt = h->chunk < h->B ? h->chunk : h->B;
     const size_t shm = (size_t)QD_K * QD_CAND_BLOCK * (sizeof(double) + sizeof(uint16_t));
     dim3 g1(qd_cand_blocks(h->R), h->C, cnt);
-    QD_HIP(hipEventRecord(a, s));
+    QD_HIP(hipEventRecord(ev.a, s));
     for (int i = 0; i < iters; ++i) {
         QD_DISPATCH_N(h->N, qd_k_candidates<NN><<<g1, dim3(QD_CAND_BLOCK), shm, s>>>(nullptr, 0, h->R, h->params, h->state, h->recs, (h->cfg.flags & QD_FLAG_VALIDATE) ? 1 : 0, h->cfg.noise_flags));
     }
     QD_HIP(hipGetLastError());
-    QD_HIP(hipEventRecord(b, s));
-    QD_HIP(hipEventSynchronize(b));
+    QD_HIP(hipEventRecord(ev.b, s));
+    QD_HIP(hipEventSynchronize(ev.b));
     float ms = 0.f;
-    QD_HIP(hipEventElapsedTime(&ms, a, b));
-    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    QD_HIP(hipEventElapsedTime(&ms, ev.a, ev.b));
     *mean_ms = ms / iters;
     return QD_OK;
 }

@@ -142,8 +142,11 @@ __device__ __forceinline__ double qd_seg_max(double v, const QdMembers& M, int s
 // One pixel per half-wave.  rec: this half's pixel record (states, their free energies from the
 // candidates kernel, v'', tunnel couplings).  On return lane m of the half holds the
 // expectation occupation of dot (m >> 2) & 7 (0 for dots >= N) and every lane the ground energy.
-template <int N>
-__device__ void qd_ground_pixel(const QdPixelRec* __restrict__ rec, QdWaveLds& W, double* occ, double* lam_out) {
+// VALIDATE additionally returns (every lane) the relative residual ||H x - lam x||_2 / ||H||_inf of the
+// winning component's eigenpair -- the on-device proof that the solve converged, in every regime.
+template <int N, bool VALIDATE = false>
+__device__ void qd_ground_pixel(const QdPixelRec* __restrict__ rec, QdWaveLds& W, double* occ, double* lam_out,
+                                double* resid_out = nullptr) {
     const int lane = threadIdx.x & 63;
     const int m = lane & 31;
     const int hb = lane & 32;
@@ -591,6 +594,25 @@ __device__ void qd_ground_pixel(const QdPixelRec* __restrict__ rec, QdWaveLds& W
     const int wroot = __builtin_ctz(win);
     const unsigned wseg = __shfl(seg, wroot, 32);
     const double p = ((wseg >> m) & 1u) ? x * x : 0.0;
+    if constexpr (VALIDATE) {
+        const bool mine = ((wseg >> m) & 1u) != 0;
+        const double xm = mine ? x : 0.0;
+        double hx = F * xm;
+        buf[lane] = xm;
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i = 0; i < QD_NBREG; ++i)
+            if (i < maxcnt) { const double xj = buf[hb + nbi[i]]; hx = fma(nbc[i], xj, hx); }
+        for (int s = QD_NBREG; s < maxcnt; ++s) {
+            const double xj = buf[hb + (int)W.nidx[s - QD_NBREG][lane]];
+            hx = fma(W.coef[s - QD_NBREG][lane], xj, hx);
+        }
+        __builtin_amdgcn_wave_barrier();
+        const double rr = mine ? hx - best * xm : 0.0;
+        const double r2 = qd_half_sum(rr * rr);
+        const double hn = -qd_half_min(-(fabs(F) + radius));          // ||H||_inf over the 32 states
+        *resid_out = sqrt(r2) / (hn > 0.0 ? hn : 1.0);
+    }
     // <n_i> = sum_m p_m n_m[i] for all dots at once by a reduce-scatter butterfly: each exchange halves
     // the number of partial sums a lane carries (4 + 2 + 1 exchanges), two more finish the single sum
     // left -- 9 cross-lane exchanges instead of 5 per dot.  Lane m ends up with dot (m >> 2) & 7.

@@ -21,13 +21,46 @@
 // a2 + a3: actions -> voltages, reward vs previous ground truth, step counter
 // (env.py:260-285, 350-462, 861-876)
 // ---------------------------------------------------------------------------
-struct QdRewardCfg { double gate_ramp_start, gate_quadratic_start, barrier_ramp_start; int max_steps; };
+struct QdRewardCfg {
+    double gate_ramp_start, gate_quadratic_start, barrier_ramp_start;
+    int max_steps;
+    // config variants (env.py:393-441, 861-876)
+    int use_deltas, sparse, curve;           // curve: 0 constant, 1 polynomial, 2 exponential, 3 linear
+    double delta_max, curve_exponent;
+    double plunger_radius, outer_plunger_radius, outer_plunger_reward_max, barrier_radius;
+};
+
+// env.py:416-441 (dense) and :393-414 (sparse) for one gate distance
+__device__ __forceinline__ double qd_gate_reward(double dist, const QdRewardCfg& rc) {
+    if (rc.sparse) {
+        if (dist <= rc.plunger_radius) return 1.0;
+        if (dist <= rc.outer_plunger_radius) {
+            const double nd = (dist - rc.plunger_radius) / (rc.outer_plunger_radius - rc.plunger_radius);
+            return rc.outer_plunger_reward_max * (1.0 - nd);
+        }
+        return 0.0;
+    }
+    double r;
+    if (dist >= rc.gate_ramp_start) r = 0.0;
+    else if (dist > rc.gate_quadratic_start)
+        r = 0.5 * ((rc.gate_ramp_start - dist) / (rc.gate_ramp_start - rc.gate_quadratic_start));
+    else {
+        const double nrm = (rc.gate_quadratic_start - dist) / rc.gate_quadratic_start;
+        double cv;
+        if (rc.curve == 1) cv = pow(nrm, rc.curve_exponent);
+        else if (rc.curve == 2) cv = (exp(rc.curve_exponent * nrm) - 1.0) / (exp(rc.curve_exponent) - 1.0);
+        else if (rc.curve == 3) cv = nrm;
+        else cv = 1.0;                                            // "constant"
+        r = 0.5 + 0.5 * cv;
+    }
+    return fmin(fmax(r, 0.0), 1.0);
+}
 
 template <int N>
 __global__ void qd_k_actions(int B, const double* __restrict__ params, double* __restrict__ state,
                              int* __restrict__ steps, const float* __restrict__ actions,
                              double* __restrict__ rewards, uint8_t* __restrict__ truncated, QdRewardCfg rc) {
-    constexpr int NB = N - 1, G = N + 1, V = 2 * N, NA = 2 * N - 1;
+    constexpr int NB = N - 1, V = 2 * N, NA = 2 * N - 1;
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= B) return;
     const QdLayout L = qd_layout(N);
@@ -40,15 +73,20 @@ __global__ void qd_k_actions(int B, const double* __restrict__ params, double* _
         a = fminf(fmaxf(a, -1.0f), 1.0f);
         const float h = (a + 1.0f) / 2.0f;                       // float32, as the reference
         const double lo = par[L.pmin + i], hi = par[L.pmax + i];
-        const double v = (double)h * (hi - lo) + lo;
+        double v;
+        if (rc.use_deltas) {
+            // env.py:864-867: the increment is formed in float32, added to the float64 current voltage
+            // with the sum stored back as float32 (in-place +=), then clipped against the float64 range
+            const float span = (float)(rc.delta_max - (-rc.delta_max)), dmin = (float)(-rc.delta_max);
+            const float d = h * span + dmin;
+            const float s32 = (float)((double)d + st[L.s_gate_v + i]);
+            v = fmin(fmax((double)s32, lo), hi);
+        } else {
+            v = (double)h * (hi - lo) + lo;
+        }
         st[L.s_gate_v + i] = v;
         const double dist = fabs(st[L.s_gate_gt + i] - v) * fabs(par[L.cgd + i * V + i]);
-        double r;
-        if (dist >= rc.gate_ramp_start) r = 0.0;
-        else if (dist > rc.gate_quadratic_start)
-            r = 0.5 * ((rc.gate_ramp_start - dist) / (rc.gate_ramp_start - rc.gate_quadratic_start));
-        else r = 0.5 + 0.5 * 1.0;                                // gate_curve_type "constant"
-        if (rewards) rewards[(size_t)e * NA + i] = fmin(fmax(r, 0.0), 1.0);
+        if (rewards) rewards[(size_t)e * NA + i] = qd_gate_reward(dist, rc);
     }
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
@@ -59,13 +97,17 @@ __global__ void qd_k_actions(int B, const double* __restrict__ params, double* _
         const double v = (double)h * (hi - lo) + lo;
         st[L.s_barrier_v + b] = v;
         const double dist = fabs(st[L.s_barrier_gt + b] - v) * par[L.alpha + b];
-        double r = (dist >= rc.barrier_ramp_start) ? 0.0 : (rc.barrier_ramp_start - dist) / rc.barrier_ramp_start;
-        if (rewards) rewards[(size_t)e * NA + N + b] = fmin(fmax(r, 0.0), 1.0);
+        double r;
+        if (rc.sparse) r = dist <= rc.barrier_radius ? 1.0 : 0.0;
+        else {
+            r = (dist >= rc.barrier_ramp_start) ? 0.0 : (rc.barrier_ramp_start - dist) / rc.barrier_ramp_start;
+            r = fmin(fmax(r, 0.0), 1.0);
+        }
+        if (rewards) rewards[(size_t)e * NA + N + b] = r;
     }
     const int s = steps[e] + 1;
     steps[e] = s;
     if (truncated) truncated[e] = s >= rc.max_steps ? 1 : 0;
-    (void)G;
 }
 
 // ---------------------------------------------------------------------------
@@ -203,11 +245,11 @@ qd_k_candidates(const int* __restrict__ env_ids, int env_base, int R, const doub
 #ifndef QD_GS_WAVES
 #define QD_GS_WAVES 4            // <= 128 VGPRs (no spills since the LDS pointers are address-space qualified) and 4 x 40 896 B of LDS per CU
 #endif
-template <int N>
+template <int N, bool VALIDATE = false>
 __global__ void __launch_bounds__(QD_GS_BLOCK, QD_GS_WAVES)
 qd_k_ground(const int* __restrict__ env_ids, int env_base, int R, const double* __restrict__ params,
             const QdPixelRec* __restrict__ recs, double* __restrict__ zraw, double* __restrict__ occ_out,
-            const double* __restrict__ state, int noise_flags) {
+            const double* __restrict__ state, int noise_flags, double* __restrict__ eig_out = nullptr) {
     constexpr int G = N + 1;
     const QdLayout L = qd_layout(N);
     const int slot = blockIdx.z;
@@ -230,8 +272,15 @@ qd_k_ground(const int* __restrict__ env_ids, int env_base, int R, const double* 
         const int pc = p < P ? p : P - 1;
         if (p0 + it * 8 >= P) break;                         // uniform for the block
         const QdPixelRec* rec = rbase + pc;
-        double occ, lam;
-        qd_ground_pixel<N>(rec, W, &occ, &lam);
+        double occ, lam, resid = 0.0;
+        qd_ground_pixel<N, VALIDATE>(rec, W, &occ, &lam, &resid);
+        if constexpr (VALIDATE) {
+            // [B][C][P][2]: ground energy of the kept-state Hamiltonian and the relative residual of the eigenpair
+            if (eig_out && (threadIdx.x & 31) == 0 && p < P) {
+                double* eo = eig_out + (((size_t)e * (N - 1) + ch) * P + p) * 2;
+                eo[0] = lam; eo[1] = resid;
+            }
+        }
         {
             // hand the sensor stage (qd_k_sensor) the pixel's constant c0 = 2 b + a (2 (Ns - v''_s) + 1):
             // F_{k+1} - F_k = c0 + 2 a (k + eta)   (closed form of the reference's energy differences).
@@ -551,7 +600,7 @@ __global__ void qd_k_write_obs(const int* __restrict__ env_ids, int R, const dou
 // ---------------------------------------------------------------------------
 // a19 + a20 + a21: one thread per env.
 // ---------------------------------------------------------------------------
-struct QdKalmanCfg { double variance_threshold, process_noise; };
+struct QdKalmanCfg { double variance_threshold, process_noise; int direct, n_out; };
 
 // pseudo-inverse of an n x n matrix (row-major, n <= 9) by one-sided Jacobi SVD,
 // numpy.linalg.pinv semantics: singular values <= 1e-15 * s_max are dropped.
@@ -629,11 +678,16 @@ template <int N>
 __device__ bool qd_kalman_update(double* mean, double* var, int i, int j, double delta, double R, QdKalmanCfg kc) {
     const int r = i < j ? i : j, c = i < j ? j : i;
     if (R > kc.variance_threshold) return false;
-    const double Pn = var[r * N + c] + kc.process_noise;
-    const double x = mean[r * N + c];
-    const double K = Pn / (Pn + R);
-    double nm = x + K * delta;
-    const double nv = (1 - K) * Pn;
+    double nm, nv;
+    if (kc.direct) {                                     // DirectUpdater.py:110-112: the prediction replaces the state
+        nm = delta; nv = R;
+    } else {
+        const double Pn = var[r * N + c] + kc.process_noise;
+        const double x = mean[r * N + c];
+        const double K = Pn / (Pn + R);
+        nm = x + K * delta;
+        nv = (1 - K) * Pn;
+    }
     nm = fmin(fmax(nm, -1.0), 1.0);
     mean[r * N + c] = nm; mean[c * N + r] = nm;
     var[r * N + c] = nv; var[c * N + r] = nv;
@@ -654,19 +708,25 @@ __global__ void qd_k_update(const int* __restrict__ env_ids, int n_env, const do
     double* mean = st + L.s_kmean;
     double* var = st + L.s_kvar;
     if (values && log_vars) {
+        const int K = kc.n_out;                                   // 3, or 2 in the legacy nearest-neighbour mode
         for (int i = 0; i < C; ++i) {
-            const float* vv = values + ((size_t)e * C + i) * 3;
-            const float* lv = log_vars + ((size_t)e * C + i) * 3;
-            // env.py:610-618: predictions negated; KalmanUpdater.py:87-90 clamp then exp
+            const float* vv = values + ((size_t)e * C + i) * K;
+            const float* lv = log_vars + ((size_t)e * C + i) * K;
+            // env.py:592-618: predictions negated; KalmanUpdater.py:87-90 clamp then exp
             double Rv[3], dl[3];
-            for (int k = 0; k < 3; ++k) {
+            for (int k = 0; k < K; ++k) {
                 dl[k] = -(double)vv[k];
                 const double c = fmin(fmax((double)lv[k], -6.0), 2.0);
                 Rv[k] = exp(c);
             }
-            qd_kalman_update<N>(mean, var, i, i + 1, dl[0], Rv[0], kc);
-            if (i + 2 < N) qd_kalman_update<N>(mean, var, i, i + 2, dl[1], Rv[1], kc);
-            if (i - 1 >= 0) qd_kalman_update<N>(mean, var, i + 1, i - 1, dl[2], Rv[2], kc);
+            if (K == 2) {                                         // KalmanUpdater.py:183-205: [RL, LR], both land on (i, i+1)
+                qd_kalman_update<N>(mean, var, i + 1, i, dl[0], Rv[0], kc);
+                qd_kalman_update<N>(mean, var, i, i + 1, dl[1], Rv[1], kc);
+            } else {
+                qd_kalman_update<N>(mean, var, i, i + 1, dl[0], Rv[0], kc);
+                if (i + 2 < N) qd_kalman_update<N>(mean, var, i, i + 2, dl[1], Rv[1], kc);
+                if (i - 1 >= 0) qd_kalman_update<N>(mean, var, i + 1, i - 1, dl[2], Rv[2], kc);
+            }
         }
         // a20: VGM = pinv(cdd_inv_full @ (-E)), E = [[cgd_est, 0], [0, 1]]  (electrons sign folded in)
         double M[G * G], Pv[G * G];

@@ -19,8 +19,12 @@ EXPORTS = [
     "qd_param_block_doubles", "qd_state_block_doubles", "qd_layout_query", "qd_create", "qd_destroy",
     "qd_last_error", "qd_bind_outputs", "qd_load_episodes", "qd_apply_actions", "qd_observe",
     "qd_update_capacitance", "qd_step", "qd_get_state", "qd_set_state", "qd_get_raw",
-    "qd_get_occupations", "qd_get_candidates", "qd_time_ground_kernel", "qd_time_candidates_kernel", "qd_chunk_envs",
+    "qd_get_occupations", "qd_get_candidates", "qd_get_eigen", "qd_get_rng_state", "qd_set_rng_state",
+    "qd_time_ground_kernel", "qd_time_candidates_kernel", "qd_chunk_envs",
 ]
+
+QD_CURVES = {"constant": 0, "polynomial": 1, "exponential": 2, "linear": 3}
+QD_UPDATE_KALMAN, QD_UPDATE_DIRECT = 0, 1
 
 
 class QdConfig(ctypes.Structure):
@@ -33,6 +37,11 @@ class QdConfig(ctypes.Structure):
         ("kalman_prior_variance", ctypes.c_double), ("kalman_prior_mean_nnn", ctypes.c_double),
         ("kalman_variance_threshold", ctypes.c_double), ("kalman_process_noise", ctypes.c_double),
         ("rng_seed", ctypes.c_uint64), ("env_id_offset", ctypes.c_int64),
+        ("use_deltas", ctypes.c_int32), ("sparse_reward", ctypes.c_int32), ("gate_curve_type", ctypes.c_int32),
+        ("update_method", ctypes.c_int32), ("cnn_outputs", ctypes.c_int32), ("reserved0", ctypes.c_int32),
+        ("delta_max", ctypes.c_double), ("gate_curve_exponent", ctypes.c_double),
+        ("plunger_radius", ctypes.c_double), ("outer_plunger_radius", ctypes.c_double),
+        ("outer_plunger_reward_max", ctypes.c_double), ("barrier_radius", ctypes.c_double),
     ]
 
 
@@ -88,6 +97,9 @@ def lib():
     L.qd_get_raw.argtypes = [vp, dp, dp]; L.qd_get_raw.restype = ctypes.c_int
     L.qd_get_occupations.argtypes = [vp, dp]; L.qd_get_occupations.restype = ctypes.c_int
     L.qd_get_candidates.argtypes = [vp, vp]; L.qd_get_candidates.restype = ctypes.c_int
+    L.qd_get_eigen.argtypes = [vp, dp]; L.qd_get_eigen.restype = ctypes.c_int
+    L.qd_get_rng_state.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]; L.qd_get_rng_state.restype = ctypes.c_int
+    L.qd_set_rng_state.argtypes = [vp, ctypes.c_uint64]; L.qd_set_rng_state.restype = ctypes.c_int
     L.qd_time_ground_kernel.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_float), vp]
     L.qd_time_ground_kernel.restype = ctypes.c_int
     L.qd_time_candidates_kernel.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_float), vp]

@@ -141,8 +141,9 @@ class EpisodeBatch:
 
 
 class DeviceSampler:
-    def __init__(self, N, qcfg, ecfg, vary_peak_width=False, peak_width_alpha=0.01):
+    def __init__(self, N, qcfg, ecfg, vary_peak_width=False, peak_width_alpha=0.01, perfect_vgm=False):
         self.N = N
+        self.perfect_vgm = bool(perfect_vgm)          # update_method "perfect" (env.py:181-182)
         self.qcfg = qcfg
         self.ecfg = ecfg
         self.plan = make_draw_plan(N, qcfg, ecfg)
@@ -256,8 +257,12 @@ class DeviceSampler:
         P[:, L.vopt:L.vopt + G] = vopt
         P[:, L.vbopt:L.vbopt + nb] = vb_opt
         # ground truth under the identity (electrons: -I) VGM, env.py:179-199
-        vgm0 = -np.eye(G)
-        virt = np.linalg.solve(vgm0[None], (vopt - origin)[:, :, None])[:, :, 0]
+        if self.perfect_vgm:
+            # qarray_base_class.py:879-901: -pinv(cdd_inv_full @ cgd_full[:, :n_gate]), negated for electrons
+            vgm0 = np.linalg.pinv(cdd_inv @ cgd[:, :, :G])
+        else:
+            vgm0 = np.broadcast_to(-np.eye(G), (n, G, G))
+        virt = np.linalg.solve(vgm0, (vopt - origin)[:, :, None])[:, :, 0]
         pgt = virt[:, :N].astype(np.float32); bgt = vb_opt.astype(np.float32); sgt = virt[:, N]
         # env.py:808-839 ranges, :842-858 start
         # NOTE the reference forms low/high in float32 (float32 ground truth combined with a
@@ -308,7 +313,7 @@ class DeviceSampler:
         else:
             P[:, L.noise + 6] = -1.0
         S = eb.state
-        S[:, L.s_vgm:L.s_vgm + G * G] = vgm0.reshape(-1)
+        S[:, L.s_vgm:L.s_vgm + G * G] = vgm0.reshape(n, -1)
         S[:, L.s_gate_v:L.s_gate_v + N] = pmin + (pmax - pmin) * a["u_start_plunger"]
         S[:, L.s_barrier_v:L.s_barrier_v + nb] = bmin + (bmax - bmin) * a["u_start_barrier"]
         S[:, L.s_gate_gt:L.s_gate_gt + N] = pgt

@@ -49,10 +49,8 @@ class QuantumDeviceEnv:
             "obs_barrier_voltages": spaces.Box(low=-1.0, high=1.0, shape=(C,), dtype=np.float32)})
         update_method = self.config["capacitance_model"]["update_method"]
         try:                                                   # env.py:680-802: same exception type
-            if update_method is None:
+            if update_method in (None, "perfect", "fake"):                 # env.py:683-689: no CNN
                 capacitance_model = None
-            elif update_method in ("perfect", "fake"):
-                raise NotImplementedError(f"update_method {update_method!r} is not built")
             elif capacitance_model is None:
                 if not capacitance_model_checkpoint:
                     raise ValueError("Capacitance model weights must be provided via capacitance_model_checkpoint "
@@ -69,7 +67,7 @@ class QuantumDeviceEnv:
             backend = VecQuantumDeviceEnv(1, num_dots=N, config_path=config_path if config_path != "env_config.yaml" else None,
                                           qarray_config_path=qarray_config_path, resolution=R,
                                           capacitance_model=capacitance_model,
-                                          seed=1234 if seed is None else seed)
+                                          seed=seed)            # None: fresh entropy per env, as the reference's unseeded RNGs
         self._b = backend
         self.current_step = 0
         self.array = types.SimpleNamespace(model=types.SimpleNamespace(cgd_full=None), barrier_alpha=None,

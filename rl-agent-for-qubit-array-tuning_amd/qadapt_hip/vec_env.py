@@ -29,27 +29,35 @@ class SyntheticCapacitanceModel:
     (values ~ N(0, 0.1^2), log_vars ~ U(-6, -2)); deterministic
     per (seed, call index)."""
 
-    def __init__(self, seed=99):
+    def __init__(self, seed=99, outputs=3):
         self.seed = seed
         self.calls = 0
+        self.outputs = outputs
 
     def __call__(self, images):
         n = images.shape[0]
         g = torch.Generator(device="cpu").manual_seed(self.seed + self.calls)
         self.calls += 1
-        values = torch.randn((n, 3), generator=g, dtype=torch.float32) * 0.1
-        log_vars = torch.rand((n, 3), generator=g, dtype=torch.float32) * 4.0 - 6.0
+        values = torch.randn((n, self.outputs), generator=g, dtype=torch.float32) * 0.1
+        log_vars = torch.rand((n, self.outputs), generator=g, dtype=torch.float32) * 4.0 - 6.0
         return values.to(images.device), log_vars.to(images.device)
 
 
 class VecQuantumDeviceEnv:
     def __init__(self, num_envs, num_dots=None, config_path=None, qarray_config_path=None,
-                 resolution=None, device=None, seed=1234, env_id_offset=0, capacitance_model=None,
+                 resolution=None, device=None, seed=None, env_id_offset=0, capacitance_model=None,
                  validate=False, env_chunk=0, reset_kalman_on_reset=False, noise=None,
                  vary_peak_width=False, peak_width_alpha=0.01, voltage_capacitance_model=None):
-        """vary_peak_width / peak_width_alpha: QarrayBaseClass ctor arguments (qarray_base_class.py:42-43).
+        """seed: base seed of the per-env device streams (PCG64(seed + global env id)) and the Philox key of
+        the stochastic stages; None draws fresh OS entropy, as the reference's unseeded generators do
+        (qarray_base_class.py:773-774, env.py:161).
+        vary_peak_width / peak_width_alpha: QarrayBaseClass ctor arguments (qarray_base_class.py:42-43).
         voltage_capacitance_model: overrides `simulator.voltage_capacitance_model.type` of the qarray
         config (None keeps the file's value; "linear" or "none")."""
+        if seed is None:
+            seed = int(np.random.SeedSequence().entropy) & 0x7FFFFFFFFFFF      # 47 bits: seed + env id stays exact
+        self.seed = int(seed)
+        self.env_id_offset = int(env_id_offset)
         self.config = load_yaml(config_path, "env_config.yaml")
         self.qconfig = load_yaml(qarray_config_path, "qarray_config.yaml")
         if voltage_capacitance_model is not None:
@@ -61,35 +69,48 @@ class VecQuantumDeviceEnv:
         self.use_barriers = bool(sim["use_barriers"])
         if not self.use_barriers:
             raise NotImplementedError("env.py only supports barrier mode for now")      # env.py:61-62
-        if sim.get("use_deltas"):
-            raise NotImplementedError("use_deltas=true is not built (reference default is false)")
-        if self.config["reward"].get("sparse_reward") or self.config["reward"].get("gate_curve_type") != "constant":
-            raise NotImplementedError("only the default dense reward with gate_curve_type 'constant' is built")
+        rew = self.config["reward"]
+        if rew.get("gate_curve_type", "constant") not in _lib.QD_CURVES:
+            raise ValueError(f"Unknown curve type: {rew.get('gate_curve_type')}")            # env.py:441
         self.resolution = int(resolution if resolution is not None else sim["resolution"])
         self.max_steps = int(sim["max_steps"])
         self.update_method = self.config["capacitance_model"]["update_method"]
-        if self.update_method not in (None, "kalman"):
-            raise NotImplementedError(f"update_method {self.update_method!r}: only null and 'kalman' are built")
-        if self.config["capacitance_model"].get("nearest_neighbour"):
-            raise NotImplementedError("nearest_neighbour (2-output) capacitance mode is not built")
+        if self.update_method in ("bayesian", "kriging", "ema"):                             # env.py:766-771
+            raise NotImplementedError(f"update_method={self.update_method!r} requires an updater module the "
+                                      "reference removed; use 'kalman' or 'direct'")
+        if self.update_method == "fake":
+            # env.py:555-559 hands fake_capacitance_model the (N, N+1) dot-only matrix, and
+            # qarray_base_class.py:917-923 then stacks rows of N+nb+2 and N+nb+1 columns: the reference's own
+            # barrier-mode path raises there, so there is no behaviour to reproduce.
+            raise ValueError("update_method 'fake' fails in the reference's barrier mode (shape mismatch in "
+                             "QarrayBaseClass._update_virtual_gate_matrix); not built")
+        if self.update_method not in (None, "kalman", "direct", "perfect"):
+            raise ValueError(f"Unknown update method: {self.update_method}")                 # env.py:788
+        self.nearest_neighbour = bool(self.config["capacitance_model"].get("nearest_neighbour"))
+        self.cnn_outputs = 2 if self.nearest_neighbour else 3
+        if self.update_method in (None, "perfect"):
+            capacitance_model = None                           # env.py:683-689: no CNN, no Kalman
         self.capacitance_model = capacitance_model
-        if self.update_method == "kalman" and capacitance_model is None:
+        if self.update_method in ("kalman", "direct") and capacitance_model is None:
             # same exception type as env.py:801-802
             raise RuntimeError("Error initialising capacitance model: update_method 'kalman' needs a "
                                "capacitance_model callable (images -> values, log_vars)")
         if not torch.cuda.is_available():
             raise RuntimeError("VecQuantumDeviceEnv needs a ROCm GPU (no CPU fallback)")
-        self.device = torch.device(device if device is not None else "cuda:0")
+        self.device = torch.device(device if device is not None else "cuda")
+        if self.device.index is None:                                  # "cuda" means the CURRENT device
+            self.device = torch.device("cuda", torch.cuda.current_device())
         self.reset_kalman_on_reset = bool(reset_kalman_on_reset)
         N = self.num_dots; R = self.resolution; B = self.num_envs
         self.N, self.R, self.B, self.C = N, R, B, N - 1
         self.L = layout(N)
         self.sampler = DeviceSampler(N, self.qconfig, self.config, vary_peak_width=vary_peak_width,
-                                     peak_width_alpha=peak_width_alpha)
-        self._rngs = [np.random.Generator(np.random.PCG64(seed + env_id_offset + e)) for e in range(B)]
+                                     peak_width_alpha=peak_width_alpha,
+                                     perfect_vgm=self.update_method == "perfect")
+        self._rngs = [np.random.Generator(np.random.PCG64(self.seed + self.env_id_offset + e)) for e in range(B)]
         # ---- library handle ---------------------------------------------------
         self._lib = _lib.lib()
-        rew = self.config["reward"]; cm = self.config["capacitance_model"]
+        cm = self.config["capacitance_model"]
         cfg = _lib.QdConfig(struct_size=ctypes.sizeof(_lib.QdConfig), n_dot=N, resolution=R, batch=B,
                             max_steps=self.max_steps, env_chunk=int(env_chunk),
                             flags=_lib.QD_FLAG_VALIDATE if validate else 0, noise_flags=self._noise_flags(noise),
@@ -99,9 +120,19 @@ class VecQuantumDeviceEnv:
                             kalman_prior_mean=0.3, kalman_prior_variance=0.5, kalman_prior_mean_nnn=0.15,
                             kalman_variance_threshold=float(cm.get("variance_threshold", 0.05)),
                             kalman_process_noise=float(cm.get("process_noise", 0.0)),
-                            rng_seed=int(seed) & 0xFFFFFFFFFFFFFFFF, env_id_offset=int(env_id_offset))
+                            rng_seed=self.seed & 0xFFFFFFFFFFFFFFFF, env_id_offset=self.env_id_offset,
+                            use_deltas=1 if sim.get("use_deltas") else 0,
+                            sparse_reward=1 if rew.get("sparse_reward") else 0,
+                            gate_curve_type=_lib.QD_CURVES[rew.get("gate_curve_type", "constant")],
+                            update_method=_lib.QD_UPDATE_DIRECT if self.update_method == "direct" else _lib.QD_UPDATE_KALMAN,
+                            cnn_outputs=self.cnn_outputs, delta_max=float(sim.get("delta_max", 0.0)),
+                            gate_curve_exponent=float(rew.get("gate_curve_exponent", 2.0)),
+                            plunger_radius=float(rew.get("plunger_radius", 0.0)),
+                            outer_plunger_radius=float(rew.get("outer_plunger_radius", 0.0)),
+                            outer_plunger_reward_max=float(rew.get("outer_plunger_reward_max", 0.0)),
+                            barrier_radius=float(rew.get("barrier_radius", 0.0)))
         self._h = ctypes.c_void_p()
-        rc = self._lib.qd_create(ctypes.byref(cfg), self.device.index or 0, ctypes.byref(self._h))
+        rc = self._lib.qd_create(ctypes.byref(cfg), self.device.index, ctypes.byref(self._h))
         _lib.check(self._h, rc, "qd_create")
         self.validate = bool(validate)
         # ---- caller-owned output tensors ---------------------------------------
@@ -117,7 +148,9 @@ class VecQuantumDeviceEnv:
                                                       self.barrier_images.data_ptr(),
                                                       self.voltages.data_ptr()), "qd_bind_outputs")
         self._params_host = np.zeros((B, self.L.size))
-        self._needs_reset = True
+        self._steps_host = np.zeros(B, np.int64)      # host mirror of the device step counters (truncation is
+        self._needs_reset = True                      # deterministic, so auto-reset needs no device read-back)
+        self.obs_count = 0
 
     # ------------------------------------------------------------------ helpers
     def _noise_flags(self, noise):
@@ -165,11 +198,12 @@ class VecQuantumDeviceEnv:
         n = img.shape[0]
         batch = img.reshape(n * self.C, 1, self.R, self.R)          # (C,1,R,R) per env, env.py:568-574
         values, log_vars = self.capacitance_model(batch)
-        values = values.to(torch.float32).reshape(n, self.C, 3)
-        log_vars = log_vars.to(torch.float32).reshape(n, self.C, 3)
+        K = self.cnn_outputs
+        values = values.to(torch.float32).reshape(n, self.C, K)
+        log_vars = log_vars.to(torch.float32).reshape(n, self.C, K)
         if env_ids is None:
             return values.contiguous(), log_vars.contiguous()
-        fv = torch.zeros((self.B, self.C, 3), dtype=torch.float32, device=self.device)
+        fv = torch.zeros((self.B, self.C, K), dtype=torch.float32, device=self.device)
         fl = torch.zeros_like(fv)
         fv[env_ids] = values; fl[env_ids] = log_vars
         return fv, fl
@@ -179,9 +213,9 @@ class VecQuantumDeviceEnv:
         """Sample new random devices for the listed envs and upload their parameter / initial
         state blocks (the device-construction half of reset(); no observation is rendered)."""
         ids = np.arange(self.B, dtype=np.int32) if env_ids is None else np.asarray(env_ids, dtype=np.int32).reshape(-1)
-        if seed is not None:
+        if seed is not None:                 # keyed by GLOBAL env id, like the constructor's streams
             for e in ids:
-                self._rngs[e] = np.random.Generator(np.random.PCG64(int(seed) + int(e)))
+                self._rngs[e] = np.random.Generator(np.random.PCG64(int(seed) + self.env_id_offset + int(e)))
         u = np.stack([self._rngs[e].random(self.sampler.n_draws) for e in ids])
         eb = self.sampler.build(u)
         self._params_host[ids] = eb.params
@@ -190,6 +224,7 @@ class VecQuantumDeviceEnv:
         rc = self._lib.qd_load_episodes(self._h, ip, int(ids.size), eb.params.ctypes.data, eb.state.ctypes.data,
                                         1 if self.reset_kalman_on_reset else 0, self._stream())
         _lib.check(self._h, rc, "qd_load_episodes")
+        self._steps_host[ids] = 0
         self._needs_reset = False
         return eb
 
@@ -251,13 +286,17 @@ class VecQuantumDeviceEnv:
             _lib.check(self._h, self._lib.qd_update_capacitance(self._h, None, 0, vp, lp, 1, st),
                        "qd_update_capacitance")
             self._keep = (actions, values, log_vars)
+        self._steps_host += 1
         truncated = self.truncated.bool()
         terminated = torch.zeros_like(truncated)
         obs = self._obs()
         if auto_reset:
-            done = torch.nonzero(truncated).reshape(-1)
-            if done.numel():
-                obs = self.reset(env_ids=done.cpu().numpy())
+            # the step counter alone decides truncation (env.py:281-285), so the host knows which envs are
+            # done without reading the device: sampling the new devices below overlaps the kernels launched above
+            done = np.nonzero(self._steps_host >= self.max_steps)[0]
+            if done.size:
+                truncated = truncated.clone()             # self.truncated is rewritten by the next step only, but be explicit
+                obs = self.reset(env_ids=done.astype(np.int32))
         return obs, self.rewards, terminated, truncated
 
     # ------------------------------------------------------------------ state access
@@ -271,6 +310,46 @@ class VecQuantumDeviceEnv:
     def set_state(self, state, steps):
         state = np.ascontiguousarray(state, dtype=np.float64); steps = np.ascontiguousarray(steps, dtype=np.int32)
         _lib.check(self._h, self._lib.qd_set_state(self._h, state.ctypes.data, steps.ctypes.data), "qd_set_state")
+        self._steps_host[:] = steps
+
+    def stagger_episodes(self):
+        """Spread the episode phases (env e is put at step e mod max_steps) so that a steady 1/max_steps of
+        the batch truncates and resets at every step -- what a long-running sampler looks like."""
+        st, _ = self.get_state()
+        self.set_state(st, (np.arange(self.B) + self.env_id_offset) % self.max_steps)
+
+    # ------------------------------------------------------------------ checkpoint
+    def get_checkpoint(self):
+        """Everything needed to continue bit-identically (SURVEY 5 "expose RNG seeds/counters"): device state and
+        step counters, the current devices' parameter blocks, every env's host generator state, the Philox
+        observation counter of the stochastic stages and the synthetic CNN's call counter if one is used."""
+        st, steps = self.get_state()
+        ser = ctypes.c_uint64(0)
+        _lib.check(self._h, self._lib.qd_get_rng_state(self._h, ctypes.byref(ser)), "qd_get_rng_state")
+        return {"state": st, "steps": steps, "params": self._params_host.copy(),
+                "rng": [g.bit_generator.state for g in self._rngs], "obs_serial": int(ser.value),
+                "seed": self.seed, "env_id_offset": self.env_id_offset,
+                "capacitance_model_calls": getattr(self.capacitance_model, "calls", None)}
+
+    def set_checkpoint(self, ck):
+        if ck["params"].shape != self._params_host.shape:
+            raise ValueError("checkpoint belongs to an env of a different shape")
+        if (ck["seed"], ck["env_id_offset"]) != (self.seed, self.env_id_offset):
+            raise ValueError("checkpoint was taken with another seed / env_id_offset (the Philox key differs)")
+        ids = np.arange(self.B, dtype=np.int32)
+        params = np.ascontiguousarray(ck["params"], dtype=np.float64)
+        state = np.ascontiguousarray(ck["state"], dtype=np.float64)
+        rc = self._lib.qd_load_episodes(self._h, ids.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), self.B,
+                                        params.ctypes.data, state.ctypes.data, 0, self._stream())
+        _lib.check(self._h, rc, "qd_load_episodes")
+        self._params_host[:] = params
+        self.set_state(state, ck["steps"])
+        for g, s_ in zip(self._rngs, ck["rng"]):
+            g.bit_generator.state = s_
+        _lib.check(self._h, self._lib.qd_set_rng_state(self._h, ctypes.c_uint64(ck["obs_serial"])), "qd_set_rng_state")
+        if ck.get("capacitance_model_calls") is not None and hasattr(self.capacitance_model, "calls"):
+            self.capacitance_model.calls = ck["capacitance_model_calls"]
+        self._needs_reset = False
 
     def device_state(self):
         """The reference's info["current_device_state"] for every env (env.py:214-222)."""
@@ -296,6 +375,13 @@ class VecQuantumDeviceEnv:
         occ = np.zeros((self.B, self.C, self.R * self.R, self.N))
         _lib.check(self._h, self._lib.qd_get_occupations(self._h, occ.ctypes.data), "qd_get_occupations")
         return occ
+
+    def eigen(self):
+        """(B,C,P,2): ground energy of each pixel's 32-state Hamiltonian and the relative residual of the
+        eigenpair the occupations came from (validate mode)."""
+        eg = np.zeros((self.B, self.C, self.R * self.R, 2))
+        _lib.check(self._h, self._lib.qd_get_eigen(self._h, eg.ctypes.data), "qd_get_eigen")
+        return eg
 
     def candidates(self):
         st = np.zeros((self.B, self.C, self.R * self.R, 32, self.N), np.int32)

@@ -6,8 +6,9 @@ Run ONCE, in the build container only (needs /root/reference):
 
     python tests/golden/make_golden.py
 
-It loads three reference source files by path and executes them unmodified:
+It loads these reference source files by path and executes them unmodified:
   * src/qadapt/capacitance_model/KalmanUpdater.py        
+  * src/qadapt/capacitance_model/DirectUpdater.py        (update_method "direct")
   * src/qarray_latched/DotArrays/GateVoltageComposer.py  
   * src/qadapt/environment/utils/vary_peak_width.py      (variable peak width)
 and stores only INPUTS and OUTPUTS (arrays) as .npz -- no reference source is
@@ -63,6 +64,36 @@ def kalman_traces():
     np.savez_compressed(os.path.join(HERE, "kalman_traces.npz"), **out)
 
 
+def updater_variant_traces():
+    """DirectUpdater.py (update_method "direct") in 3-output mode and both updaters in the legacy
+    2-output nearest_neighbour mode (include_nnn=False, env.py:784) -- the reference classes themselves."""
+    K = _load(f"{REF}/src/qadapt/capacitance_model/KalmanUpdater.py", "ref_kalman")
+    D = _load(f"{REF}/src/qadapt/capacitance_model/DirectUpdater.py", "ref_direct")
+    out = {}
+    cases = [("direct", D.DirectCapacitanceUpdater, 4, 10, 3, 11), ("direct", D.DirectCapacitanceUpdater, 8, 12, 3, 12),
+             ("direct", D.DirectCapacitanceUpdater, 6, 8, 2, 13), ("kalman", K.KalmanCapacitanceUpdater, 4, 10, 2, 14),
+             ("kalman", K.KalmanCapacitanceUpdater, 8, 9, 2, 15)]
+    for case, (name, cls, n_dots, steps, n_out, seed) in enumerate(cases):
+        rng = np.random.default_rng(seed)
+        k = cls(n_dots=n_dots, prior_mean=0.3, prior_variance=0.5, variance_threshold=0.05, process_noise=0.0,
+                include_nnn=(n_out == 3), prior_mean_nnn=0.15)
+        C = n_dots - 1
+        values = rng.normal(0.0, 0.1, size=(steps, C, n_out))
+        values[rng.random(values.shape) < 0.05] *= 40.0
+        log_vars = rng.uniform(-8.0, -1.5, size=(steps, C, n_out))
+        means = np.zeros((steps, n_dots, n_dots)); varis = np.zeros_like(means); full = np.zeros_like(means)
+        for t in range(steps):
+            for i in range(C):
+                outs = [(-float(values[t, i, j]), float(log_vars[t, i, j])) for j in range(n_out)]
+                k.update_from_scan(left_dot=i, ml_outputs=outs)
+            means[t] = k.means; varis[t] = k.variances; full[t] = k.get_full_matrix()
+        out[f"c{case}_kind"] = np.array(name); out[f"c{case}_n_dots"] = np.array(n_dots)
+        out[f"c{case}_values"] = values; out[f"c{case}_log_vars"] = log_vars
+        out[f"c{case}_means"] = means; out[f"c{case}_variances"] = varis; out[f"c{case}_full"] = full
+    out["n_cases"] = np.array(len(cases))
+    np.savez_compressed(os.path.join(HERE, "updater_variants.npz"), **out)
+
+
 def sweep_grids():
     G = _load(f"{REF}/src/qarray_latched/DotArrays/GateVoltageComposer.py", "ref_gvc")
     out = {}
@@ -110,7 +141,11 @@ if __name__ == "__main__":
     if "--only-peak-widths" in __import__("sys").argv:
         peak_widths()
         raise SystemExit(0)
+    if "--only-updater-variants" in __import__("sys").argv:
+        updater_variant_traces()
+        raise SystemExit(0)
     kalman_traces()
+    updater_variant_traces()
     sweep_grids()
     peak_widths()
     print("golden fixtures written to", HERE)

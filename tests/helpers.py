@@ -132,3 +132,27 @@ def host_layout(N):
     out = np.zeros(n, np.int32)
     h.qdh_layout(N, _p(out, ctypes.c_int))
     return dict(zip(LAYOUT_FIELDS, out.tolist()))
+
+
+def pixel_spectrum(dev, vgm, origin, gate_v, sensor_v, barrier_v, window, ch, R, states=None):
+    """Per pixel of one CSD channel: the two lowest eigenvalues of the oracle's 32-state Hamiltonian and
+    ||H||_inf.  rel_gap = (lam1 - lam0) / ||H||_inf says how well float64 resolves the ground vector
+    (eigenvector error ~ eps / rel_gap): the parity tests compare occupations / images pixel by pixel
+    where rel_gap > GAP_MIN and require every pixel that misses the tolerance to lie below it."""
+    N = dev.n_dot
+    vg = O.sweep_voltages(vgm, origin, gate_v, sensor_v, ch, -window, window, R)
+    vb = np.broadcast_to(np.asarray(barrier_v, float), (R * R, N - 1))
+    v_ext = np.concatenate([vg, vb], axis=1)
+    if states is None:
+        states, _ = O.candidate_states(v_ext, dev.cdd_inv_full, dev.cgd_full, N)
+    if getattr(dev, "vc", None) is not None:
+        raise NotImplementedError("pixel_spectrum: constant-capacitance model only")
+    F = O.free_energy_states(v_ext, dev.cdd_inv_full, dev.cgd_full, states, N)
+    tc = O.tunnel_couplings(O.effective_barrier_potential(vg, vb, dev.Cbg, dev.Cbb), dev.tc_base, dev.alpha)
+    Hm = F[:, :, None] * np.eye(states.shape[1]) + O.tunnel_hamiltonian(tc, states)
+    w = np.linalg.eigvalsh(Hm)
+    hn = np.abs(Hm).sum(axis=2).max(axis=1)
+    return dict(lam0=w[:, 0], lam1=w[:, 1], hnorm=hn, rel_gap=(w[:, 1] - w[:, 0]) / hn, tcmax=tc.max(axis=1))
+
+
+GAP_MIN = 1e-7          # relative gap below which the ground vector is not comparable pixel by pixel

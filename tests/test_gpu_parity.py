@@ -29,6 +29,44 @@ def _cnn(B, C, seed):
     return v, lv, (torch.as_tensor(v).cuda(), torch.as_tensor(lv).cuda())
 
 
+def _image_ok(oe, img, oimg, tol=2e-6):
+    """Image parity of one oracle env's observation: every pixel within `tol`, unless some pixel of that env is
+    unresolvable in float64 (rel_gap <= GAP_MIN) -- then the shared percentiles may move, and only the bulk is
+    required to agree.  Returns (ok, worst, n_unresolvable)."""
+    N, R = oe.N, oe.R
+    unres = 0
+    for ch in range(N - 1):
+        sp = H.pixel_spectrum(oe.dev, oe.vgm_at_obs, oe.origin, oe.gate_v, oe.sensor_gt, oe.barrier_v, oe.window, ch, R)
+        unres += int((sp["rel_gap"] <= H.GAP_MIN).sum())
+    d = np.abs(img - oimg)
+    if unres == 0:
+        return bool(d.max() <= tol), float(d.max()), 0
+    return bool((d <= tol).mean() > 0.98), float(d.max()), unres
+
+
+def _check_channel(tag, dev, sv, ch, R, cand, occ, raw, eig):
+    """One CSD channel of one env against the C oracle: kept states bit-exact; eigenpair residual at round-off in
+    every pixel; energy equal to the oracle's lowest eigenvalue up to round-off of ||H||; occupations and sensor
+    signal within 1e-6 in every pixel the oracle can resolve -- a pixel that misses must be near-degenerate.
+    Returns (reference raw signal, resolvable mask, worst occupation error, worst relative signal error)."""
+    ref = OC.csd_channel(dev, sv.vgm, dev.origin, sv.gate_v, sv.sensor_gt, sv.barrier_v, dev.window, ch, R)
+    assert np.array_equal(cand, ref["states"]), tag
+    sp = H.pixel_spectrum(dev, sv.vgm, dev.origin, sv.gate_v, sv.sensor_gt, sv.barrier_v, dev.window, ch, R,
+                          states=ref["states"])
+    assert eig[:, 1].max() <= 1e-12, (tag, eig[:, 1].max())
+    assert np.all(np.abs(eig[:, 0] - sp["lam0"]) <= 1e-12 * sp["hnorm"]), tag
+    ok = sp["rel_gap"] > H.GAP_MIN
+    d_occ = np.abs(occ - ref["occ"]).max(axis=1)
+    d_sig = np.abs(raw - ref["z"]) / np.maximum(np.abs(ref["z"]), 1e-3)
+    assert np.all(sp["rel_gap"][d_occ > 1e-6] <= H.GAP_MIN), (tag, d_occ[ok].max())
+    assert np.all(sp["rel_gap"][d_sig > 1e-6] <= H.GAP_MIN), (tag, d_sig[ok].max())
+    tot = occ.sum(axis=1)                                      # hopping conserves the total charge
+    assert np.all(np.abs(tot - np.round(tot))[ok] < 1e-6), tag
+    wo = float(d_occ[ok].max()) if ok.any() else 0.0
+    ws = float(d_sig[ok].max()) if ok.any() else 0.0
+    return ref["z"], ok, wo, ws
+
+
 def _resolvable(oe, limit=1e6):
     """True if the tunnel couplings at the oracle env's current voltages stay below `limit`
     (beyond that a dense float64 eigh no longer resolves the spectrum: |H| ~ tc * n)."""
@@ -69,29 +107,29 @@ def test_csd_pipeline_matches_oracle(N, R, mode):
     raw, plohi = env.raw()
     occ = env.occupations()
     cand = env.candidates()
+    eig = env.eigen()
     img = env.global_image.cpu().numpy()
+    worst_occ = worst_sig = 0.0
     for e in range(B):
         par = env._params_host[e]
         dev = H.dev_view(N, par); sv = H.state_view(N, st[e])
-        ref_raw = np.zeros((N - 1, R * R))
+        ref_raw = np.zeros((N - 1, R * R)); comparable = np.zeros((N - 1, R * R), bool)
         for ch in range(N - 1):
-            ref = OC.csd_channel(dev, sv.vgm, dev.origin, sv.gate_v, sv.sensor_gt, sv.barrier_v, dev.window, ch, R)
-            # integer charge states: bit-exact
-            assert np.array_equal(cand[e, ch], ref["states"]), (e, ch)
-            # occupations: expectation values; compare where the spectrum is resolvable in float64
-            ok = ref["tc"].max(axis=1) < 1e6
-            assert np.allclose(occ[e, ch][ok], ref["occ"][ok], rtol=1e-6, atol=1e-6), (e, ch)
-            assert np.allclose(raw[e, ch][ok], ref["z"][ok], rtol=1e-6, atol=1e-9), (e, ch)
-            ref_raw[ch] = ref["z"]
+            z, ok, wo, ws = _check_channel((N, R, mode, e, ch), dev, sv, ch, R, cand[e, ch], occ[e, ch], raw[e, ch], eig[e, ch])
+            worst_occ = max(worst_occ, wo); worst_sig = max(worst_sig, ws)
+            ref_raw[ch] = z; comparable[ch] = ok
         # percentiles of the GPU's own raw data: exact numpy semantics
         assert plohi[e, 0] == np.percentile(raw[e], 0.5) and plohi[e, 1] == np.percentile(raw[e], 99.5)
         # normalised image (R,R,C) float32
         mine = O.normalise_image(raw[e].reshape(N - 1, R, R).transpose(1, 2, 0))
         assert np.array_equal(img[e], mine)
-        if np.all([True]):
+        if comparable.all():
+            # the whole-oracle image (its own percentiles): every pixel within 2e-6 when every pixel of the env
+            # is resolvable (a single unresolvable pixel can move the shared percentiles)
             full = O.normalise_image(ref_raw.reshape(N - 1, R, R).transpose(1, 2, 0))
-            resolvable = np.abs(full - img[e]) <= 2e-6
-            assert resolvable.mean() > 0.999
+            assert np.abs(full - img[e]).max() <= 2e-6, np.abs(full - img[e]).max()
+    print(f"[parity] N={N} R={R} {mode}: max |occ - oracle| = {worst_occ:.2e}, max rel signal error = {worst_sig:.2e} "
+          f"over resolvable pixels (rel_gap > {H.GAP_MIN})")
     # per-agent views
     pim = env.plunger_images.cpu().numpy(); bim = env.barrier_images.cpu().numpy()
     for e in range(B):
@@ -121,9 +159,8 @@ def test_episode_matches_oracle_env(N, R):
         oobs = oe.reset(so, v0[e], l0[e])
         oenvs.append(oe)
         assert np.allclose(obs["obs_gate_voltages"][e].cpu().numpy(), oobs["obs_gate_voltages"], atol=1e-6)
-        if _resolvable(oe):
-            d = np.abs(obs["image"][e].cpu().numpy() - oobs["image"])
-            assert (d <= 2e-6).mean() > 0.995
+        ok, worst, unres = _image_ok(oe, obs["image"][e].cpu().numpy(), oobs["image"])
+        assert ok, (e, worst, unres)
     ds = env.device_state()
     for e, oe in enumerate(oenvs):
         assert np.allclose(ds["kalman_means"][e], oe.kalman.means, rtol=1e-12, atol=1e-15)
@@ -158,9 +195,8 @@ def test_episode_matches_oracle_env(N, R):
             assert np.isclose(ds["sensor_ground_truth"][e], oe.sensor_gt, rtol=1e-8)
             assert np.allclose(obs["obs_gate_voltages"][e].cpu().numpy(), oobs["obs_gate_voltages"], atol=1e-6)
             assert np.allclose(obs["obs_barrier_voltages"][e].cpu().numpy(), oobs["obs_barrier_voltages"], atol=1e-6)
-            if _resolvable(oe):
-                d = np.abs(obs["image"][e].cpu().numpy() - oobs["image"])
-                assert (d <= 2e-6).mean() > 0.99, (step, e, (d > 2e-6).sum())
+            ok, worst, unres = _image_ok(oe, obs["image"][e].cpu().numpy(), oobs["image"])
+            assert ok, (step, e, worst, unres)
     env.close()
 
 
@@ -236,33 +272,37 @@ def test_action_clipping_and_rewards_far_regime():
 
 @pytest.mark.parametrize("N,R", [(4, 16), (8, 8)])
 def test_wild_regime_ground_energy_not_above_oracle(N, R):
-    """Far from the ground truth the couplings reach 1e10+ and a dense float64 eigh no longer
-    resolves the spectrum, so occupations are not comparable pixel by pixel.  What must still
-    hold: the kept charge states are bit-exact, and our ground state is a valid one -- its
-    Rayleigh quotient (recomputed in float64 from our occupations is not available, so we check
-    the total charge is an integer sector and occupations are within the candidate range)."""
+    """Far from the ground truth the couplings reach 1e10+ and a dense float64 eigh resolves the spectrum only
+    to ~1e-16 ||H||, so occupations are not comparable pixel by pixel there.  What is well defined, and checked
+    in EVERY pixel: the kept charge states are bit-exact; the eigenpair the kernel used has an on-device
+    residual at round-off level; its energy is not above the oracle's lowest eigenvalue (+ round-off of ||H||);
+    occupations lie inside the candidate range; wherever the gap is resolvable the total charge is an integer."""
     B = 2
     env = _env(B, N, R)
     env.reset()            # random start voltages: anywhere in the 80-100 V plunger range
     st, _ = env.get_state()
-    occ = env.occupations(); cand = env.candidates()
-    for e in range(B):
-        par = env._params_host[e]
-        dev = H.dev_view(N, par); sv = H.state_view(N, st[e])
-        # note: reset() has already updated the VGM after the observation; re-observe with it
+    # reset() has already updated the VGM after the observation; re-observe with it
     from qadapt_hip import _lib
     _lib.check(env._h, env._lib.qd_observe(env._h, None, 0, env._stream()), "qd_observe")
-    occ = env.occupations(); cand = env.candidates()
+    occ = env.occupations(); cand = env.candidates(); eig = env.eigen()
+    wild = 0
     for e in range(B):
         par = env._params_host[e]
         dev = H.dev_view(N, par); sv = H.state_view(N, st[e])
         for ch in range(N - 1):
             ref = OC.csd_channel(dev, sv.vgm, dev.origin, sv.gate_v, sv.sensor_gt, sv.barrier_v, dev.window, ch, R)
             assert np.array_equal(cand[e, ch], ref["states"])
+            sp = H.pixel_spectrum(dev, sv.vgm, dev.origin, sv.gate_v, sv.sensor_gt, sv.barrier_v, dev.window, ch, R,
+                                  states=ref["states"])
+            wild += int((sp["tcmax"] >= 1e6).sum())
+            assert eig[e, ch, :, 1].max() <= 1e-12, (e, ch, eig[e, ch, :, 1].max())
+            assert np.all(eig[e, ch, :, 0] <= sp["lam0"] + 1e-12 * sp["hnorm"]), (e, ch)
             lo = cand[e, ch].min(axis=1); hi = cand[e, ch].max(axis=1)
             assert np.all(occ[e, ch] >= lo - 1e-9) and np.all(occ[e, ch] <= hi + 1e-9)
             tot = occ[e, ch].sum(axis=1)
-            assert np.mean(np.abs(tot - np.round(tot)) < 1e-6) > 0.98
+            ok = sp["rel_gap"] > H.GAP_MIN
+            assert np.all(np.abs(tot - np.round(tot))[ok] < 1e-6)
+    assert wild > 0, "the scene was meant to contain wild-regime pixels"
     env.close()
 
 
@@ -478,8 +518,10 @@ def test_dataset_generator_format_and_values(tmp_path):
     eff = dev.cdd_inv_full @ dev.cgd_full[:, :G] @ sv.vgm
     assert np.allclose(eff[:N, :N], T[0], atol=1e-9)
     ref = O.get_obs_images(dev, sv.vgm, dev.origin, sv.gate_v, sv.barrier_v, 0.0, dev.window, R)
-    ok = np.abs(images[0] - ref) <= 1e-5 * (1 + np.abs(ref))
-    assert ok.mean() > 0.99
+    bad = np.abs(images[0] - ref) > 1e-5 * (1 + np.abs(ref))               # (R,R,C)
+    for ch in range(N - 1):                                                # a pixel that misses must be near-degenerate
+        sp = H.pixel_spectrum(dev, sv.vgm, dev.origin, sv.gate_v, 0.0, sv.barrier_v, dev.window, ch, R)
+        assert np.all(sp["rel_gap"][bad[:, :, ch].reshape(-1)] <= H.GAP_MIN), ch
     gen.close()
 
 
@@ -559,20 +601,12 @@ def test_randomised_scene_sweep(seed):
     env.set_state(st, steps)
     from qadapt_hip import _lib
     _lib.check(env._h, env._lib.qd_observe(env._h, None, 0, env._stream()), "qd_observe")
-    raw, _ = env.raw(); occ = env.occupations(); cand = env.candidates()
+    raw, _ = env.raw(); occ = env.occupations(); cand = env.candidates(); eig = env.eigen()
     checked = 0
     for e in range(B):
         dev = H.dev_view(N, env._params_host[e]); sv = H.state_view(N, st[e])
         for ch in range(N - 1):
-            ref = OC.csd_channel(dev, sv.vgm, dev.origin, sv.gate_v, sv.sensor_gt, sv.barrier_v, dev.window, ch, R)
-            assert np.array_equal(cand[e, ch], ref["states"]), (N, R, mode, e, ch)
-            ok = ref["tc"].max(axis=1) < 1e6
+            _, ok, _, _ = _check_channel((N, R, mode, e, ch), dev, sv, ch, R, cand[e, ch], occ[e, ch], raw[e, ch], eig[e, ch])
             checked += int(ok.sum())
-            assert np.allclose(occ[e, ch][ok], ref["occ"][ok], rtol=1e-6, atol=1e-6), (N, R, mode, e, ch)
-            assert np.allclose(raw[e, ch][ok], ref["z"][ok], rtol=1e-6, atol=1e-9), (N, R, mode, e, ch)
-            # total charge of the ground state is an integer (hopping conserves it) wherever one sector wins clearly
-            if ok.sum() >= 8:
-                tot = occ[e, ch][ok].sum(axis=1)
-                assert np.mean(np.abs(tot - np.round(tot)) < 1e-6) > 0.9
     assert checked > 0
     env.close()

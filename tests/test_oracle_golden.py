@@ -38,3 +38,19 @@ def test_sweep_grids_match_reference(golden_dir):
         vg = O.sweep_voltages(g[f"c{c}_vgm"], g[f"c{c}_origin"], g[f"c{c}_gate_voltages"],
                               float(g[f"c{c}_sensor"]), ch, -w, w, R)
         assert np.array_equal(vg, g[f"c{c}_vg_flat"])
+
+
+def test_direct_and_nn_mode_updaters_match_reference(golden_dir):
+    """update_method "direct" (DirectUpdater.py) and the legacy 2-output nearest_neighbour mode of both
+    updaters, against traces of the reference classes themselves."""
+    g = np.load(os.path.join(golden_dir, "updater_variants.npz"))
+    for c in range(int(g["n_cases"])):
+        n = int(g[f"c{c}_n_dots"]); kind = str(g[f"c{c}_kind"])
+        values = g[f"c{c}_values"]; log_vars = g[f"c{c}_log_vars"]
+        cls = O.DirectOracle if kind == "direct" else O.KalmanOracle
+        k = cls(n, include_nnn=values.shape[-1] == 3)
+        for t in range(values.shape[0]):
+            k.update_from_cnn(values[t], log_vars[t])
+            assert np.array_equal(k.means, g[f"c{c}_means"][t]), (c, t)
+            assert np.array_equal(k.vars, g[f"c{c}_variances"][t]), (c, t)
+            assert np.array_equal(k.full_matrix(), g[f"c{c}_full"][t]), (c, t)
