@@ -19,6 +19,42 @@ def shard_env_ids(rank: int, world: int, envs_per_rank: int):
     return rank * envs_per_rank, envs_per_rank
 
 
+def bucket_cost(n_dots: int, resolution: int = 64) -> float:
+    """Relative cost of one env-step of an n-dot array: (n-1) channels of R*R pixels, each a 32-state
+    eigenproblem plus a candidate search whose tree grows with n (measured: 8-dot pixels cost ~1.9x a 4-dot
+    pixel).  Only ratios matter; used to balance mixed-N buckets over ranks."""
+    return (n_dots - 1) * resolution * resolution * (0.55 + 0.18 * n_dots)
+
+
+def shard_mixed(counts: dict, rank: int, world: int, resolution: int = 64):
+    """BASELINE config 5: a ragged batch is bucketed by dot count and EVERY bucket is split over all
+    ranks, so each GPU gets the same mix.  Global env ids run bucket after bucket (ascending n_dots); inside a
+    bucket rank r owns a contiguous slice.  The remainder envs of a bucket (count % world) go, most expensive
+    bucket first, to the ranks that are currently least loaded (cost-weighted), so no rank collects all the
+    left-overs.  Returns {n_dots: (first_global_env_id, n_envs)} for `rank`; every global id is owned by
+    exactly one rank (tests/test_shard.py)."""
+    if not (0 <= rank < world):
+        raise ValueError(f"rank {rank} outside world {world}")
+    order = sorted(counts)
+    base = {}
+    off = 0
+    for n in order:
+        base[n] = off
+        off += int(counts[n])
+    share = {n: [int(counts[n]) // world] * world for n in order}
+    load = [sum(share[n][r] * bucket_cost(n, resolution) for n in order) for r in range(world)]
+    for n in sorted(order, key=lambda k: -bucket_cost(k, resolution)):
+        rem = int(counts[n]) % world
+        for r in sorted(range(world), key=lambda k: (load[k], k))[:rem]:      # one each, to the least loaded ranks
+            share[n][r] += 1
+            load[r] += bucket_cost(n, resolution)
+    out = {}
+    for n in order:
+        first = base[n] + sum(share[n][:rank])
+        out[n] = (first, share[n][rank])
+    return out
+
+
 def init(backend: str, local_rank: int = 0):
     import torch
     import torch.distributed as dist

@@ -86,7 +86,7 @@ def test_stacked_spaces():
 def test_frame_stacking_on_the_real_env():
     from qadapt_hip.vec_env import VecQuantumDeviceEnv, SyntheticCapacitanceModel
     B, N, R, F = 4, 4, 16, 3
-    env = VecQuantumDeviceEnv(B, num_dots=N, resolution=R, capacitance_model=SyntheticCapacitanceModel(2))
+    env = VecQuantumDeviceEnv(B, num_dots=N, resolution=R, seed=1234, capacitance_model=SyntheticCapacitanceModel(2))
     fs = BatchedFrameStacking(B, N, R, F, device=env.device)
     frames = []
     out = fs.push(env.reset(), reset_mask=torch.ones(B, dtype=torch.bool))
