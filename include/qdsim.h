@@ -34,6 +34,8 @@ extern "C" {
 #define QD_ERR_NOMEM 4
 
 #define QD_FLAG_VALIDATE 1    /* keep per-pixel candidate records and occupations  */
+#define QD_FLAG_PIXEL_SEARCH 2 /* a9 by the per-pixel search only (default: one search per 8x8 pixel tile where the
+                                 grid is fine enough, with an exact per-pixel redo pass; same results, A/B switch) */
 
 /* Stochastic stages.  The generators are counter-based Philox streams, so
  * results are reproducible per (rng_seed, global env id, observation number, channel, pixel)
@@ -161,6 +163,9 @@ int qd_get_candidates(qd_handle* h, int32_t* states_host);
  * Hamiltonian (what jnp.linalg.eigh returns first, ground_state.py:150) and the relative residual
  * ||H x - lambda x||_2 / ||H||_inf of the eigenpair the occupations were formed from. */
 int qd_get_eigen(qd_handle* h, double* eig_host);
+/* Counters of the tile-shared candidate search since qd_create (QD_FLAG_VALIDATE): tiles searched, tiles handed
+ * whole to the per-pixel search, single pixels redone for a near-tie at the 32nd state, sum of superset sizes. */
+int qd_get_search_stats(qd_handle* h, uint64_t* out4);
 /* Checkpointing of the stochastic stages (SURVEY 5 "expose RNG seeds/counters"): the Philox
  * counter word that numbers the observations rendered so far by this handle. */
 int qd_get_rng_state(const qd_handle* h, uint64_t* obs_serial);

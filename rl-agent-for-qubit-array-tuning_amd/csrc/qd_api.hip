@@ -21,6 +21,8 @@ struct qd_handle {
     size_t recs_envs;                       // envs the recs buffer holds
     float *gimg, *pimg, *bimg, *volt;
     unsigned long long* tel; int tel_words;
+    unsigned long long* tstats;             // tile-search counters (validate mode)
+    int tile_search;                        // 1: tile-shared candidate search + exact redo pass; 0: per-pixel search only
     unsigned long long obs_serial;
     char err[512];
 };
@@ -134,7 +136,12 @@ extern "C" int qd_create(const qd_config* cfg, int device, qd_handle** out) {
     }
     if ((cfg->flags & QD_FLAG_VALIDATE) || (cfg->noise_flags & QD_NOISE_LATCH))
         QD_HIP(hipMalloc(&h->occ, sizeof(double) * (size_t)h->B * h->C * h->P * h->N));
+    // the tile-shared search pays off where neighbouring pixels are close in voltage (fine grids) and needs >= 32
+    // candidates valid across a tile (N >= 4); otherwise every pixel is searched on its own
+    h->tile_search = (h->N >= 4 && h->R >= 32 && !(cfg->flags & QD_FLAG_PIXEL_SEARCH)) ? 1 : 0;
     if (cfg->flags & QD_FLAG_VALIDATE) {
+        QD_HIP(hipMalloc(&h->tstats, sizeof(unsigned long long) * 4));
+        QD_HIP(hipMemset(h->tstats, 0, sizeof(unsigned long long) * 4));
         QD_HIP(hipMalloc(&h->eig, sizeof(double) * 2 * (size_t)h->B * h->C * h->P));
         QD_HIP(hipMemset(h->eig, 0, sizeof(double) * 2 * (size_t)h->B * h->C * h->P));
     }
@@ -163,7 +170,7 @@ extern "C" int qd_create(const qd_config* cfg, int device, qd_handle** out) {
 extern "C" int qd_destroy(qd_handle* h) {
     if (!h) return QD_ERR_ARG;
     QdDeviceGuard guard_(h->device);
-    void* bufs[] = {h->params, h->state, h->steps, h->zraw, h->plohi, h->recs, h->occ, h->tel, h->eig};
+    void* bufs[] = {h->params, h->state, h->steps, h->zraw, h->plohi, h->recs, h->occ, h->tel, h->eig, h->tstats};
     for (void* b : bufs) if (b) (void)hipFree(b);
     delete h;
     return QD_OK;
@@ -260,6 +267,25 @@ static QdNoiseCfg qd_noise_cfg(const qd_handle* h) {
     return nz;
 }
 
+// a5/a8/a9/a10 for `cnt` envs starting at list position `base`: tile-shared search + exact redo pass, or the
+// per-pixel search alone
+static int qd_launch_candidates(qd_handle* h, const int32_t* env_ids, int base, int cnt, hipStream_t s) {
+    const size_t shm = (size_t)QD_K * QD_CAND_BLOCK * (sizeof(double) + sizeof(uint16_t));
+    const int sorted = (h->cfg.flags & QD_FLAG_VALIDATE) ? 1 : 0;
+    dim3 g1(qd_cand_blocks(h->R), h->C, cnt);
+    if (h->tile_search) {
+        const int tiles = ((h->R + 7) / 8) * ((h->R + 7) / 8);
+        dim3 gt(tiles, h->C, cnt);
+        QD_DISPATCH_N(h->N, qd_k_tile_candidates<NN><<<gt, dim3(64), 0, s>>>(env_ids, base, h->R, h->params, h->state, h->recs,
+                                                                               sorted, h->cfg.noise_flags, h->tstats));
+        QD_HIP(hipGetLastError());
+    }
+    QD_DISPATCH_N(h->N, qd_k_candidates<NN><<<g1, dim3(QD_CAND_BLOCK), shm, s>>>(env_ids, base, h->R, h->params, h->state, h->recs,
+                                                                                  sorted, h->cfg.noise_flags, h->tile_search));
+    QD_HIP(hipGetLastError());
+    return QD_OK;
+}
+
 static int qd_launch_ground(qd_handle* h, const int32_t* env_ids, int base, int cnt, hipStream_t s) {
     dim3 g2((h->P + QD_GS_PPB - 1) / QD_GS_PPB, h->C, cnt);
     if (h->eig) {
@@ -281,7 +307,6 @@ extern "C" int qd_observe(qd_handle* h, const int32_t* env_ids, int n, void* str
     if (n == 0) return QD_OK;
     if (n > h->B) return qd_fail(h, QD_ERR_ARG, "qd_observe: n > batch");
     const QdLayout& L = h->L;
-    const size_t shm = (size_t)QD_K * QD_CAND_BLOCK * (sizeof(double) + sizeof(uint16_t));
     h->obs_serial++;
     if (h->cfg.noise_flags & QD_NOISE_SENSOR) {
         const int nt = n * h->C;
@@ -290,10 +315,9 @@ extern "C" int qd_observe(qd_handle* h, const int32_t* env_ids, int n, void* str
     }
     for (int base = 0; base < n; base += h->chunk) {
         const int cnt = (n - base < h->chunk) ? n - base : h->chunk;
-        dim3 g1(qd_cand_blocks(h->R), h->C, cnt);
-        QD_DISPATCH_N(h->N, qd_k_candidates<NN><<<g1, dim3(QD_CAND_BLOCK), shm, s>>>(env_ids, base, h->R, h->params, h->state, h->recs, (h->cfg.flags & QD_FLAG_VALIDATE) ? 1 : 0, h->cfg.noise_flags));
-        QD_HIP(hipGetLastError());
-        int rc = qd_launch_ground(h, env_ids, base, cnt, s);
+        int rc = qd_launch_candidates(h, env_ids, base, cnt, s);
+        if (rc) return rc;
+        rc = qd_launch_ground(h, env_ids, base, cnt, s);
         if (rc) return rc;
     }
     if (h->cfg.noise_flags & QD_NOISE_LATCH) {
@@ -410,6 +434,15 @@ extern "C" int qd_get_eigen(qd_handle* h, double* eig) {
     return QD_OK;
 }
 
+extern "C" int qd_get_search_stats(qd_handle* h, uint64_t* out4) {
+    if (!h || !out4) return QD_ERR_ARG;
+    if (!h->tstats) return qd_fail(h, QD_ERR_STATE, "qd_get_search_stats needs QD_FLAG_VALIDATE");
+    QD_ON_DEVICE(h);
+    QD_HIP(hipDeviceSynchronize());
+    QD_HIP(hipMemcpy(out4, h->tstats, sizeof(unsigned long long) * 4, hipMemcpyDeviceToHost));
+    return QD_OK;
+}
+
 extern "C" int qd_get_rng_state(const qd_handle* h, uint64_t* obs_serial) {
     if (!h || !obs_serial) return QD_ERR_ARG;
     *obs_serial = h->obs_serial;
@@ -445,13 +478,8 @@ extern "C" int qd_time_candidates_kernel(qd_handle* h, int iters, float* mean_ms
     QdEventPair ev;
     if (!ev.ok) return qd_fail(h, QD_ERR_HIP, "hipEventCreate");
     const int cnt = h->chunk < h->B ? h->chunk : h->B;
-    const size_t shm = (size_t)QD_K * QD_CAND_BLOCK * (sizeof(double) + sizeof(uint16_t));
-    dim3 g1(qd_cand_blocks(h->R), h->C, cnt);
     QD_HIP(hipEventRecord(ev.a, s));
-    for (int i = 0; i < iters; ++i) {
-        QD_DISPATCH_N(h->N, qd_k_candidates<NN><<<g1, dim3(QD_CAND_BLOCK), shm, s>>>(nullptr, 0, h->R, h->params, h->state, h->recs, (h->cfg.flags & QD_FLAG_VALIDATE) ? 1 : 0, h->cfg.noise_flags));
-    }
-    QD_HIP(hipGetLastError());
+    for (int i = 0; i < iters; ++i) { int rc = qd_launch_candidates(h, nullptr, 0, cnt, s); if (rc) return rc; }
     QD_HIP(hipEventRecord(ev.b, s));
     QD_HIP(hipEventSynchronize(ev.b));
     float ms = 0.f;

@@ -131,6 +131,8 @@ __device__ __forceinline__ bool qd_radial_replaced(const double* par, const doub
     return d1 > full || d2 > full;
 }
 
+#include "qd_tile.h"        // tile-shared candidate search (uses qd_radial_replaced)
+
 // Random telegraph process along the row-major raster of one (env, channel): two-state Markov
 // chain, P(0->1) = p01, P(1->0) = p10, started from its stationary distribution; bit p of the
 // output = state at pixel p.  One thread per (env, channel) -- the chain is serial by nature.
@@ -168,7 +170,8 @@ __global__ void qd_k_telegraph(const int* __restrict__ env_ids, int n_env, int C
 template <int N>
 __global__ void __launch_bounds__(QD_CAND_BLOCK, QD_CAND_WAVES)
 qd_k_candidates(const int* __restrict__ env_ids, int env_base, int R, const double* __restrict__ params,
-                const double* __restrict__ state, QdPixelRec* __restrict__ recs, int sort_output, int noise_flags) {
+                const double* __restrict__ state, QdPixelRec* __restrict__ recs, int sort_output, int noise_flags,
+                int only_flagged) {
     constexpr int G = N + 1, NB = N - 1, V = 2 * N;
     const QdLayout L = qd_layout(N);
     const int slot = blockIdx.z;
@@ -195,6 +198,8 @@ qd_k_candidates(const int* __restrict__ env_ids, int env_base, int R, const doub
     if (!inside) return;
     if (qd_radial_replaced(spar, sst, L, ch, noise_flags)) return;   // image will be pure noise: nothing to solve
     QdPixelRec* rec = recs + ((size_t)slot * (N - 1) + ch) * P + p;
+    // second pass behind the tile search (qd_tile.h): only the pixels it left to the exact per-pixel search
+    if (only_flagged && rec->nvalid != QD_T_REDO) return;
     double vd[N], ncont[N], isa;
     {
         double v_ext[V], vpp[G], tc[NB];

@@ -47,8 +47,9 @@ class VecQuantumDeviceEnv:
     def __init__(self, num_envs, num_dots=None, config_path=None, qarray_config_path=None,
                  resolution=None, device=None, seed=None, env_id_offset=0, capacitance_model=None,
                  validate=False, env_chunk=0, reset_kalman_on_reset=False, noise=None,
-                 vary_peak_width=False, peak_width_alpha=0.01, voltage_capacitance_model=None):
-        """seed: base seed of the per-env device streams (PCG64(seed + global env id)) and the Philox key of
+                 vary_peak_width=False, peak_width_alpha=0.01, voltage_capacitance_model=None, pixel_search=False):
+        """pixel_search: a9 by the per-pixel search only (A/B switch; the default runs one search per 8x8 tile).
+        seed: base seed of the per-env device streams (PCG64(seed + global env id)) and the Philox key of
         the stochastic stages; None draws fresh OS entropy, as the reference's unseeded generators do
         (qarray_base_class.py:773-774, env.py:161).
         vary_peak_width / peak_width_alpha: QarrayBaseClass ctor arguments (qarray_base_class.py:42-43).
@@ -113,7 +114,7 @@ class VecQuantumDeviceEnv:
         cm = self.config["capacitance_model"]
         cfg = _lib.QdConfig(struct_size=ctypes.sizeof(_lib.QdConfig), n_dot=N, resolution=R, batch=B,
                             max_steps=self.max_steps, env_chunk=int(env_chunk),
-                            flags=_lib.QD_FLAG_VALIDATE if validate else 0, noise_flags=self._noise_flags(noise),
+                            flags=(_lib.QD_FLAG_VALIDATE if validate else 0) | (_lib.QD_FLAG_PIXEL_SEARCH if pixel_search else 0), noise_flags=self._noise_flags(noise),
                             gate_ramp_start=float(rew["gate_ramp_start"]),
                             gate_quadratic_start=float(rew["gate_quadratic_start"]),
                             barrier_ramp_start=float(rew["barrier_ramp_start"]),
@@ -382,6 +383,14 @@ class VecQuantumDeviceEnv:
         eg = np.zeros((self.B, self.C, self.R * self.R, 2))
         _lib.check(self._h, self._lib.qd_get_eigen(self._h, eg.ctypes.data), "qd_get_eigen")
         return eg
+
+    def search_stats(self):
+        """Tile-search counters (validate mode): tiles, tiles redone whole, pixels redone, mean superset size."""
+        out = (ctypes.c_uint64 * 4)()
+        _lib.check(self._h, self._lib.qd_get_search_stats(self._h, out), "qd_get_search_stats")
+        t = max(int(out[0]), 1)
+        return {"tiles": int(out[0]), "tiles_redone": int(out[1]), "pixels_redone": int(out[2]),
+                "mean_superset": int(out[3]) / t}
 
     def candidates(self):
         st = np.zeros((self.B, self.C, self.R * self.R, 32, self.N), np.int32)
