@@ -164,8 +164,9 @@ int qd_get_candidates(qd_handle* h, int32_t* states_host);
  * ||H x - lambda x||_2 / ||H||_inf of the eigenpair the occupations were formed from. */
 int qd_get_eigen(qd_handle* h, double* eig_host);
 /* Counters of the tile-shared candidate search since qd_create (QD_FLAG_VALIDATE): tiles searched, tiles handed
- * whole to the per-pixel search, single pixels redone for a near-tie at the 32nd state, sum of superset sizes. */
-int qd_get_search_stats(qd_handle* h, uint64_t* out4);
+ * whole to the per-pixel search, single pixels redone, sum of superset sizes, pixels redone for < 32 valid states;
+ * [8 + r]: tiles handed over by reason r (1 ranges, 2 seeds, 3 frontier overflow, 4 too few leaves, 5 superset size). */
+int qd_get_search_stats(qd_handle* h, uint64_t* out16);
 /* Checkpointing of the stochastic stages (SURVEY 5 "expose RNG seeds/counters"): the Philox
  * counter word that numbers the observations rendered so far by this handle. */
 int qd_get_rng_state(const qd_handle* h, uint64_t* obs_serial);

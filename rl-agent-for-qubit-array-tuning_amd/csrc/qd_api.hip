@@ -140,8 +140,8 @@ extern "C" int qd_create(const qd_config* cfg, int device, qd_handle** out) {
     // candidates valid across a tile (N >= 4); otherwise every pixel is searched on its own
     h->tile_search = (h->N >= 4 && h->R >= 32 && !(cfg->flags & QD_FLAG_PIXEL_SEARCH)) ? 1 : 0;
     if (cfg->flags & QD_FLAG_VALIDATE) {
-        QD_HIP(hipMalloc(&h->tstats, sizeof(unsigned long long) * 4));
-        QD_HIP(hipMemset(h->tstats, 0, sizeof(unsigned long long) * 4));
+        QD_HIP(hipMalloc(&h->tstats, sizeof(unsigned long long) * 16));
+        QD_HIP(hipMemset(h->tstats, 0, sizeof(unsigned long long) * 16));
         QD_HIP(hipMalloc(&h->eig, sizeof(double) * 2 * (size_t)h->B * h->C * h->P));
         QD_HIP(hipMemset(h->eig, 0, sizeof(double) * 2 * (size_t)h->B * h->C * h->P));
     }
@@ -434,12 +434,12 @@ extern "C" int qd_get_eigen(qd_handle* h, double* eig) {
     return QD_OK;
 }
 
-extern "C" int qd_get_search_stats(qd_handle* h, uint64_t* out4) {
-    if (!h || !out4) return QD_ERR_ARG;
+extern "C" int qd_get_search_stats(qd_handle* h, uint64_t* out16) {
+    if (!h || !out16) return QD_ERR_ARG;
     if (!h->tstats) return qd_fail(h, QD_ERR_STATE, "qd_get_search_stats needs QD_FLAG_VALIDATE");
     QD_ON_DEVICE(h);
     QD_HIP(hipDeviceSynchronize());
-    QD_HIP(hipMemcpy(out4, h->tstats, sizeof(unsigned long long) * 4, hipMemcpyDeviceToHost));
+    QD_HIP(hipMemcpy(out16, h->tstats, sizeof(unsigned long long) * 16, hipMemcpyDeviceToHost));
     return QD_OK;
 }
 

@@ -22,7 +22,7 @@
 
 #if defined(__HIPCC__)
 
-#define QD_T_FCAP 512          // frontier capacity (partial states per level)
+#define QD_T_FCAP 512          // frontier capacity (partial states per level; 2 x 512 x 12 B of LDS)
 #define QD_T_SCAP 256          // superset capacity
 #define QD_T_REDO (-1)         // QdPixelRec.nvalid marker: pixel left to the exact per-pixel search
 
@@ -101,7 +101,8 @@ __device__ __forceinline__ void qd_tile_point(const QdTileLds& T, const double* 
 
 // ---------------------------------------------------------------------------------------------
 // grid = (tiles, C, n_env), block = 64 (one wavefront = one 8x8 pixel tile)
-// stats (optional, 4 counters): tiles, tiles redone whole, lanes redone for a near-tie, sum of |S|
+// stats (optional, 16 counters): tiles, tiles redone whole, lanes redone, sum of |S|, lanes redone for < 32 valid
+// states in S; [8 + reason]: tiles redone by reason (1 ranges, 2 seeds, 3 frontier overflow, 4 too few leaves, 5 |S|)
 // ---------------------------------------------------------------------------------------------
 template <int N>
 __global__ void __launch_bounds__(64)
@@ -155,6 +156,7 @@ qd_k_tile_candidates(const int* __restrict__ env_ids, int env_base, int R, const
     const double y0 = (double)(ty * 8 - yr), y1 = (double)(min(ty * 8 + 7, R - 1) - yr);
     const double Xh = fmax(-x0, x1), Yh = fmax(-y0, y1);
     bool fail = false;
+    int why = 0;                                                           // first reason a tile was handed over (statistics)
     double rho;
     double v0[N];                                                          // v' of the reference pixel (uniform)
     {
@@ -164,8 +166,10 @@ qd_k_tile_candidates(const int* __restrict__ env_ids, int env_base, int R, const
         for (int i = 0; i < N; ++i) {
             v0[i] = qd_rl(vd[i], 27);
             mref[i] = qd_rl(ncont[i], 27);
-            dxv[i] = qd_rl(vd[i], 25) - qd_rl(vd[i], 24);                  // one pixel step in x (0 if the tile is one column wide)
-            dyv[i] = qd_rl(vd[i], 32) - qd_rl(vd[i], 24);                  // one pixel step in y
+            // one pixel step in x / y from the tile's first pixel, which is always on the image (lanes off the image
+            // repeat an edge pixel, so the step is 0 exactly when the tile is one column / row wide)
+            dxv[i] = qd_rl(vd[i], 1) - qd_rl(vd[i], 0);
+            dyv[i] = qd_rl(vd[i], 8) - qd_rl(vd[i], 0);
             const double r = ((vd[i] - v0[i]) - xs * dxv[i]) - ys * dyv[i];
             r1 += fabs(r);
             if (lane == 0) T.m[i] = mref[i];
@@ -197,11 +201,11 @@ qd_k_tile_candidates(const int* __restrict__ env_ids, int env_base, int R, const
         lo_[i] = max(fmn - 1, 0); const int hi = fmx + 2;
         alo_[i] = max(fmx - 1, 0); ahi_[i] = fmn + 2;
         nd_[i] = hi - lo_[i] + 1;
-        if (nd_[i] > 8 || ahi_[i] < alo_[i]) fail = true;                  // digits must fit 3 bits (packed range tests)
+        if (nd_[i] > 8 || ahi_[i] < alo_[i]) { fail = true; why = 1; }      // digits must fit 3 bits (packed range tests)
         allvalid_count *= (unsigned long long)(ahi_[i] >= alo_[i] ? ahi_[i] - alo_[i] + 1 : 0);
         if (lane == 0) { T.lo[i] = lo_[i]; T.nd[i] = nd_[i]; }
     }
-    if (allvalid_count < (unsigned long long)QD_K) fail = true;
+    if (allvalid_count < (unsigned long long)QD_K) { fail = true; why = 1; }
     __builtin_amdgcn_wave_barrier();
 
     // ---- 3. greedy lattice point cg (uniform), option costs, product set of seeds -------------------
@@ -320,7 +324,7 @@ qd_k_tile_candidates(const int* __restrict__ env_ids, int env_base, int R, const
         // of the CANONICAL absolute energies that define the reference order (~N^2 ulps of |E|)
         margin = 2.0 * rho * (double)maxdc + 1e-11 * escale + 1e-12 * qd_wmax_d(fabs(Ecg));
         const double Mh = (lane < prod) ? (pn - pn_ref) + qd_plane_max(pa, pb, x0, x1, y0, y1) + margin : INFINITY;
-        if (prod < QD_K) fail = true;
+        if (prod < QD_K) { fail = true; why = 2; }
         else {
             // 32nd smallest of the seeds' maxima
             int below = 0;
@@ -330,7 +334,7 @@ qd_k_tile_candidates(const int* __restrict__ env_ids, int env_base, int R, const
             }
             const unsigned long long sel = __ballot(below == QD_K - 1 && lane < prod);
             Tpp = sel ? qd_rl(Mh, __builtin_ctzll(sel)) : INFINITY;
-            if (!(Tpp < INFINITY)) fail = true;
+            if (!(Tpp < INFINITY)) { fail = true; why = 2; }
         }
     }
 
@@ -382,18 +386,18 @@ qd_k_tile_candidates(const int* __restrict__ env_ids, int env_base, int R, const
                     nout += __builtin_popcountll(km);
                 }
             }
-            if (nout > QD_T_FCAP) fail = true;
+            if (nout > QD_T_FCAP) { fail = true; why = 3; }
             nfront = nout; cur ^= 1;
             __builtin_amdgcn_wave_barrier();
         }
     }
 
     // ---- 5. T (bisection on the count of maxima) and the superset S --------------------------------
-    int nS = 0;
-    if (nfront < QD_K) fail = true;
+    int nS = 0, nSfront = 0;
+    if (!fail && nfront < QD_K) { fail = true; why = 4; }
     if (!fail) {
         constexpr int CH = QD_T_FCAP / 64;
-        double Mh[CH], mh[CH], Dv[CH], pav[CH], pbv[CH];
+        double Mh[CH];
         // packed all-valid range test: digit >= alo - lo and <= ahi - lo in every nibble (digits < 8)
         uint32_t vlo = 0, vhi = 0;
 #pragma unroll
@@ -404,18 +408,17 @@ qd_k_tile_candidates(const int* __restrict__ env_ids, int env_base, int R, const
         double mlo = INFINITY;
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
-            Mh[c] = INFINITY; mh[c] = INFINITY; Dv[c] = 0.0; pav[c] = 0.0; pbv[c] = 0.0;
+            Mh[c] = INFINITY;
             const int node = c * 64 + lane;
             if (c * 64 < nfront && node < nfront) {
                 const uint32_t code = T.u.f.code[cur][node];
-                double pn, pa, pb;
-                qd_tile_point<N>(T, U, code, pn, pa, pb);
-                const double D = pn - pn_ref;
-                Dv[c] = D; pav[c] = pa; pbv[c] = pb;
-                mh[c] = D + qd_plane_min(pa, pb, x0, x1, y0, y1) - margin;
                 const bool av = ((((code | 0x88888888u) - vlo) & 0x88888888u) == 0x88888888u) &&
                                 ((((vhi | 0x88888888u) - code) & 0x88888888u) == 0x88888888u);
-                if (av) Mh[c] = D + qd_plane_max(pa, pb, x0, x1, y0, y1) + margin;
+                if (av) {
+                    double pn, pa, pb;
+                    qd_tile_point<N>(T, U, code, pn, pa, pb);
+                    Mh[c] = (pn - pn_ref) + qd_plane_max(pa, pb, x0, x1, y0, y1) + margin;
+                }
                 mlo = fmin(mlo, Mh[c]);
             }
         }
@@ -428,28 +431,44 @@ qd_k_tile_candidates(const int* __restrict__ env_ids, int env_base, int R, const
             if (cnt >= QD_K) thi = mid; else tlo = mid;
         }
         const double Tt = thi;
-        // S: first the states whose maximum is within T (likely kept everywhere), then the rest with m <= T
+        // S = {m <= T}: the states whose maximum is within T (kept in most pixels) fill S from the front, the others
+        // from the back, so that the per-lane buffers below fill up with likely keepers first
+        int nfrontS = 0, nbackS = 0;
+#pragma unroll 1
+        for (int c = 0; c < CH; ++c) {
+            if (c * 64 >= nfront) break;
+            const int node = c * 64 + lane;
+            bool take = false, likely = false;
+            uint32_t code = 0; double D = 0.0, pa = 0.0, pb = 0.0;
+            if (node < nfront) {
+                code = T.u.f.code[cur][node];
+                double pn;
+                qd_tile_point<N>(T, U, code, pn, pa, pb);
+                D = pn - pn_ref;
+                take = (D + qd_plane_min(pa, pb, x0, x1, y0, y1) - margin) <= Tt;
+                double mhc = INFINITY;
 #pragma unroll
-        for (int pass = 0; pass < 2; ++pass) {
-#pragma unroll
-            for (int c = 0; c < CH; ++c) {
-                if (c * 64 >= nfront) continue;
-                const bool take = (mh[c] <= Tt) && ((Mh[c] <= Tt) == (pass == 0));
-                const unsigned long long km = __ballot(take);
-                const int pos = nS + qd_lane_prefix(km);
-                if (take && pos < QD_T_SCAP) {
-                    const int node = c * 64 + lane;
-                    T.scode[pos] = T.u.f.code[cur][node]; T.sD[pos] = Dv[c]; T.sa[pos] = pav[c]; T.sb[pos] = pbv[c];
-                }
-                nS += __builtin_popcountll(km);
+                for (int cc = 0; cc < CH; ++cc) if (cc == c) mhc = Mh[cc];
+                likely = take && (mhc <= Tt);
             }
+            const unsigned long long kf = __ballot(likely), kb = __ballot(take && !likely);
+            const int tot = nfrontS + nbackS + __builtin_popcountll(kf) + __builtin_popcountll(kb);
+            if (tot <= QD_T_SCAP) {
+                int pos = -1;
+                if (likely) pos = nfrontS + qd_lane_prefix(kf);
+                else if (take) pos = QD_T_SCAP - 1 - (nbackS + qd_lane_prefix(kb));
+                if (pos >= 0) { T.scode[pos] = code; T.sD[pos] = D; T.sa[pos] = pa; T.sb[pos] = pb; }
+            }
+            nfrontS += __builtin_popcountll(kf); nbackS += __builtin_popcountll(kb);
         }
-        if (nS > QD_T_SCAP || nS < QD_K) fail = true;
+        nS = nfrontS + nbackS;
+        nSfront = nfrontS;
+        if (nS > QD_T_SCAP || nS < QD_K) { fail = true; why = 5; }
         __builtin_amdgcn_wave_barrier();
     }
     if (stats && lane == 0) {
         atomicAdd(&stats[0], 1ull);
-        if (fail) atomicAdd(&stats[1], 1ull);
+        if (fail) { atomicAdd(&stats[1], 1ull); atomicAdd(&stats[8 + why], 1ull); }
         atomicAdd(&stats[3], (unsigned long long)nS);
     }
     if (fail) {                                                            // the whole tile goes to the exact per-pixel search
@@ -467,7 +486,8 @@ qd_k_tile_candidates(const int* __restrict__ env_ids, int env_base, int R, const
     double gE[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}; int gS[4] = {0, 8, 16, 24};
     double maxE = -INFINITY; int maxS = 0, maxG = 0, count = 0;
     double eout = INFINITY;                                                  // lowest energy NOT kept
-    for (int s = 0; s < nS; ++s) {
+    for (int si = 0; si < nS; ++si) {
+        const int s = si < nSfront ? si : QD_T_SCAP - 1 - (si - nSfront);      // front part, then the back part
         const uint32_t code = T.scode[s];
         const bool valid = ((((code | 0x88888888u) - blo) & 0x88888888u) == 0x88888888u) &&
                            ((((bhi | 0x88888888u) - code) & 0x88888888u) == 0x88888888u);
@@ -508,7 +528,10 @@ qd_k_tile_candidates(const int* __restrict__ env_ids, int env_base, int R, const
     // a lane whose boundary is closer than what the arithmetic can tell apart is redone exactly
     const double amb = 2.0 * margin;
     const bool redo = (count < QD_K) || !(eout - maxE > amb);
-    if (stats) { const unsigned long long rm = __ballot(redo && inside); if (lane == 0 && rm) atomicAdd(&stats[2], (unsigned long long)__builtin_popcountll(rm)); }
+    if (stats) {
+        const unsigned long long rm = __ballot(redo && inside), rc = __ballot(count < QD_K && inside);
+        if (lane == 0 && rm) { atomicAdd(&stats[2], (unsigned long long)__builtin_popcountll(rm)); atomicAdd(&stats[4], (unsigned long long)__builtin_popcountll(rc)); }
+    }
     if (!inside) return;
     if (redo) { rec->nvalid = QD_T_REDO; return; }
 

@@ -386,11 +386,13 @@ class VecQuantumDeviceEnv:
 
     def search_stats(self):
         """Tile-search counters (validate mode): tiles, tiles redone whole, pixels redone, mean superset size."""
-        out = (ctypes.c_uint64 * 4)()
+        out = (ctypes.c_uint64 * 16)()
         _lib.check(self._h, self._lib.qd_get_search_stats(self._h, out), "qd_get_search_stats")
         t = max(int(out[0]), 1)
         return {"tiles": int(out[0]), "tiles_redone": int(out[1]), "pixels_redone": int(out[2]),
-                "mean_superset": int(out[3]) / t}
+                "pixels_redone_few_states": int(out[4]), "mean_superset": int(out[3]) / t,
+                "tiles_redone_by_reason": {k: int(out[8 + i]) for i, k in
+                                           enumerate(("", "ranges", "seeds", "frontier", "leaves", "superset")) if k}}
 
     def candidates(self):
         st = np.zeros((self.B, self.C, self.R * self.R, 32, self.N), np.int32)
