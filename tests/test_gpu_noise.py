@@ -118,3 +118,84 @@ def test_latching_identity_when_always_accepted_and_hysteresis_otherwise():
     for (e, ch, p) in idx[:50]:
         assert np.array_equal(occ[e, ch, p], occ[e, ch, p - 1])
     env.close()
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Sample-by-sample: the kernels against the numpy restatement of the same rules on the same Philox stream
+# (oracle/qd_noise_oracle.py).  Stays "unverified against qarray" (source absent), but no longer self-certified.
+# ---------------------------------------------------------------------------------------------------------
+def _noise_params(P, L, e):
+    return dict(white_amp=P[e, L.noise + 0], tel_p01=P[e, L.noise + 1], tel_p10=P[e, L.noise + 2], tel_amp=P[e, L.noise + 3],
+                zero_radius=P[e, L.noise + 4], ramp_distance=P[e, L.noise + 5],
+                full_noise_distance=P[e, L.noise + 6] if P[e, L.noise + 6] > 0 else None, max_amplitude=P[e, L.noise + 7])
+
+
+@pytest.mark.parametrize("flags", [["sensor"], ["radial"], ["latch"], ["sensor", "radial", "latch"]])
+def test_noisy_observation_matches_numpy_restatement(flags):
+    import qd_noise_oracle as NO
+    import qd_oracle_c as OC
+    from qadapt_hip.vec_env import VecQuantumDeviceEnv, SyntheticCapacitanceModel
+    B, N, R, seed, off = 3, 4, 24, 99, 40
+    env = VecQuantumDeviceEnv(B, num_dots=N, resolution=R, seed=seed, env_id_offset=off, noise=flags, validate=True,
+                              capacitance_model=SyntheticCapacitanceModel(2))
+    env.reset()
+    # env 0 near its ground truth, env 1 in the radial ramp, env 2 beyond full_noise_distance
+    raw, st = _observe_at(env, [1.5, 27.0, 70.0])
+    occ = env.occupations()
+    ck = env.get_checkpoint()
+    serial = ck["obs_serial"]                               # the observation just rendered
+    P = env._params_host; L = env.L
+    for e in range(B):
+        dev = H.dev_view(N, P[e]); sv = H.state_view(N, st[e])
+        s = NO.Stream(seed, off + e, serial)
+        nz = _noise_params(P, L, e)
+        p_leads = P[e, L.pleads:L.pleads + N]; p_inter = P[e, L.pinter:L.pinter + N * N].reshape(N, N)
+        for ch in range(N - 1):
+            det = OC.csd_channel(dev, sv.vgm, dev.origin, sv.gate_v, sv.sensor_gt, sv.barrier_v, dev.window, ch, R)
+            z, used = NO.observe_channel(dev, nz, s, ch, R, sv.vgm, dev.origin, sv.gate_v, sv.sensor_gt, sv.barrier_v,
+                                         dev.window, sv.gate_gt, det["occ"], set(flags), p_leads, p_inter)
+            ok = det["tc"].max(axis=1) < 1e6
+            if "radial" in flags and NO.radial_replaced(sv.gate_v[ch], sv.gate_v[ch + 1], sv.gate_gt[ch], sv.gate_gt[ch + 1],
+                                                        nz["full_noise_distance"]):
+                assert np.allclose(raw[e, ch], z, rtol=1e-12, atol=1e-12), (flags, e, ch)     # pure N(0,1) image
+                continue
+            if "latch" in flags:
+                # the latched occupations themselves: exact copies of the held pixel's values
+                assert np.allclose(occ[e, ch][ok], used[ok], rtol=1e-6, atol=1e-6), (flags, e, ch)
+                assert (np.abs(used - det["occ"]).max(axis=1) > 1e-3).any() or e != 0      # latching did happen somewhere near truth
+            assert np.allclose(raw[e, ch][ok], z[ok], rtol=1e-6, atol=1e-9), (flags, e, ch, np.abs(raw[e, ch][ok] - z[ok]).max())
+    env.close()
+
+
+def test_mixed_n_with_latching_config5():
+    """BASELINE config 5 in miniature: a ragged batch N in {2,4,6,8} with the latched model on, sharded two ways;
+    every bucket's images equal a homogeneous env with the same global env ids, and latching changed something."""
+    import torch
+    from qadapt_hip.mixed import MixedVecQuantumDeviceEnv
+    from qadapt_hip.vec_env import VecQuantumDeviceEnv, SyntheticCapacitanceModel
+    counts = {2: 3, 4: 3, 6: 2, 8: 2}
+    R = 16
+    fac = lambda n: SyntheticCapacitanceModel(40 + n)
+    shards = [MixedVecQuantumDeviceEnv(counts, resolution=R, seed=7, rank=r, world=2, capacitance_model_factory=fac, noise=["latch"])
+              for r in range(2)]
+    seen = []
+    for sh in shards:
+        sh.reset()
+        for n, e in sh.buckets.items():
+            first, cnt = sh.assignment[n]
+            seen += list(range(first, first + cnt))
+            ref = VecQuantumDeviceEnv(cnt, num_dots=n, resolution=R, seed=7, env_id_offset=first, noise=["latch"],
+                                      capacitance_model=fac(n))
+            ref.reset()
+            assert np.array_equal(e.global_image.cpu().numpy(), ref.global_image.cpu().numpy()), (n, first)
+            plain = VecQuantumDeviceEnv(cnt, num_dots=n, resolution=R, seed=7, env_id_offset=first, capacitance_model=fac(n))
+            plain.reset()
+            if n >= 4:
+                assert not np.array_equal(e.global_image.cpu().numpy(), plain.global_image.cpu().numpy())
+            ref.close(); plain.close()
+        acts = {n: torch.zeros((e.B, 2 * n - 1), device="cuda") for n, e in sh.buckets.items()}
+        out = sh.step(acts, auto_reset=True)
+        assert set(out) == set(sh.buckets)
+    assert sorted(seen) == list(range(sum(counts.values())))
+    for sh in shards:
+        sh.close()
