@@ -145,6 +145,7 @@ def test_noisy_observation_matches_numpy_restatement(flags):
     ck = env.get_checkpoint()
     serial = ck["obs_serial"]                               # the observation just rendered
     P = env._params_host; L = env.L
+    latched_any = False
     for e in range(B):
         dev = H.dev_view(N, P[e]); sv = H.state_view(N, st[e])
         s = NO.Stream(seed, off + e, serial)
@@ -162,8 +163,9 @@ def test_noisy_observation_matches_numpy_restatement(flags):
             if "latch" in flags:
                 # the latched occupations themselves: exact copies of the held pixel's values
                 assert np.allclose(occ[e, ch][ok], used[ok], rtol=1e-6, atol=1e-6), (flags, e, ch)
-                assert (np.abs(used - det["occ"]).max(axis=1) > 1e-3).any() or e != 0      # latching did happen somewhere near truth
+                latched_any |= bool((used != det["occ"]).any())
             assert np.allclose(raw[e, ch][ok], z[ok], rtol=1e-6, atol=1e-9), (flags, e, ch, np.abs(raw[e, ch][ok] - z[ok]).max())
+    assert latched_any or "latch" not in flags, "the scene was meant to contain latched pixels"
     env.close()
 
 
@@ -178,7 +180,7 @@ def test_mixed_n_with_latching_config5():
     fac = lambda n: SyntheticCapacitanceModel(40 + n)
     shards = [MixedVecQuantumDeviceEnv(counts, resolution=R, seed=7, rank=r, world=2, capacitance_model_factory=fac, noise=["latch"])
               for r in range(2)]
-    seen = []
+    seen = []; changed = False
     for sh in shards:
         sh.reset()
         for n, e in sh.buckets.items():
@@ -190,12 +192,12 @@ def test_mixed_n_with_latching_config5():
             assert np.array_equal(e.global_image.cpu().numpy(), ref.global_image.cpu().numpy()), (n, first)
             plain = VecQuantumDeviceEnv(cnt, num_dots=n, resolution=R, seed=7, env_id_offset=first, capacitance_model=fac(n))
             plain.reset()
-            if n >= 4:
-                assert not np.array_equal(e.global_image.cpu().numpy(), plain.global_image.cpu().numpy())
+            changed |= not np.array_equal(e.raw()[0], plain.raw()[0])
             ref.close(); plain.close()
         acts = {n: torch.zeros((e.B, 2 * n - 1), device="cuda") for n, e in sh.buckets.items()}
         out = sh.step(acts, auto_reset=True)
         assert set(out) == set(sh.buckets)
     assert sorted(seen) == list(range(sum(counts.values())))
+    assert changed, "latching was meant to change at least one bucket's raw signal"
     for sh in shards:
         sh.close()
