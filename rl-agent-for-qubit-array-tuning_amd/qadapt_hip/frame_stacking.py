@@ -140,3 +140,67 @@ def stacked_observation_space(obs_space, num_frames: int):
                               shape=(num_frames,), dtype=voltage_space.dtype),
         "attention_mask": spaces.Box(low=0, high=1, shape=(num_frames,), dtype=np.int8),
     })
+
+
+# ---------------------------------------------------------------------------------------------------------
+# RLlib ConnectorV2 wrapper (env-to-module).  The reference registers `CustomFrameStackingEnvToModule`
+# (custom_frame_stacking.py:297, train.py:497-539), which rebuilds the stack on the host from each agent's episode
+# object.  This connector hands the policy forward the stack that already sits on the GPU: one tensor per policy
+# module, all B envs and all agents of that kind stacked on the batch axis, no host copy, no per-agent Python objects.
+# ---------------------------------------------------------------------------------------------------------
+try:                                            # pragma: no cover - ray is absent in the build container
+    from ray.rllib.connectors.connector_v2 import ConnectorV2 as _ConnectorBase
+    HAVE_RLLIB = True
+except Exception:
+    HAVE_RLLIB = False
+
+    class _ConnectorBase:                       # same constructor / call shape as ConnectorV2
+        def __init__(self, input_observation_space=None, input_action_space=None, **kwargs):
+            self.input_observation_space = input_observation_space
+            self.input_action_space = input_action_space
+            self.observation_space = self.recompute_output_observation_space(input_observation_space, input_action_space) \
+                if input_observation_space is not None else None
+
+        def recompute_output_observation_space(self, input_observation_space, input_action_space):
+            return input_observation_space
+
+
+class DeviceFrameStackingConnector(_ConnectorBase):
+    """env-to-module connector over a BatchedFrameStacking.  `source()` returns the observation dict of the batched
+    env for the step being processed (VecQuantumDeviceEnv.step's first return value) and optionally the mask of envs
+    that have just been reset; policy modules are addressed by the reference's mapping rule -- agent ids containing
+    "plunger" / "barrier" (training/utils/policy_mapping.py:14-17)."""
+
+    def __init__(self, input_observation_space=None, input_action_space=None, *, stacker: BatchedFrameStacking = None,
+                 source=None, plunger_module="plunger_policy", barrier_module="barrier_policy", **kwargs):
+        self.stacker, self.source = stacker, source
+        self.num_frames = stacker.F if stacker is not None else kwargs.pop("num_frames", 1)
+        self.plunger_module, self.barrier_module = plunger_module, barrier_module
+        super().__init__(input_observation_space, input_action_space, **kwargs)
+
+    def recompute_output_observation_space(self, input_observation_space, input_action_space):
+        """Per-agent spaces -> stacked spaces for plunger agents, unchanged for barrier agents (:251-294)."""
+        if input_observation_space is None:
+            return None
+        return spaces.Dict({a: stacked_observation_space(s, self.num_frames) for a, s in input_observation_space.items()})
+
+    def __call__(self, *, rl_module=None, batch=None, episodes=None, explore=None, shared_data=None, **kwargs):
+        """Fills batch["obs"][module] with DEVICE tensors, agents of one kind flattened onto the batch axis in
+        (env, agent) order:
+            plunger module: image (B*N, F, R, R, 2), voltage (B*N, F), attention_mask (B*N, F) int8
+            barrier module: image (B*(N-1), R, R, 1), voltage (B*(N-1), 1)
+        `episodes` is not consulted: the history lives in the stacker."""
+        got = self.source()
+        obs, reset_mask = got if isinstance(got, tuple) else (got, None)
+        st = self.stacker.push(obs, reset_mask=reset_mask)
+        B, N, F = self.stacker.B, self.stacker.N, self.stacker.F
+        batch = {} if batch is None else batch
+        out = batch.setdefault("obs", {})
+        out[self.plunger_module] = {"image": st["image"].reshape((B * N, F) + tuple(st["image"].shape[3:])),
+                                    "voltage": st["voltage"].reshape(B * N, F),
+                                    "attention_mask": st["attention_mask"].reshape(B * N, F)}
+        if "barrier_images" in st:
+            bi = st["barrier_images"]
+            out[self.barrier_module] = {"image": bi.reshape((B * (N - 1),) + tuple(bi.shape[2:])),
+                                        "voltage": st["barrier_voltage"].reshape(B * (N - 1), 1)}
+        return batch

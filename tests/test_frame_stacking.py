@@ -102,3 +102,38 @@ def test_frame_stacking_on_the_real_env():
         assert torch.equal(out["image"][:, :, f], frames[len(frames) - F + f])
     assert out["image"].is_cuda and out["image"].shape == (B, N, F, R, R, 2)
     env.close()
+
+
+def test_connector_hands_over_device_stacks_per_policy_module():
+    """The ConnectorV2-shaped env-to-module wrapper: one tensor per policy module, identical to the reference's
+    per-agent host stacks (oracle restatement), without consulting episode objects."""
+    from qadapt_hip.frame_stacking import DeviceFrameStackingConnector
+    rng = np.random.default_rng(4)
+    B, N, R, F, T = 2, 3, 5, 3, 4
+    fs = BatchedFrameStacking(B, N, R, F, device="cpu")
+    feed = {}
+    pl = spaces.Dict({"image": spaces.Box(0.0, 1.0, (R, R, 2), np.float32), "voltage": spaces.Box(-1.0, 1.0, (1,), np.float32)})
+    ba = spaces.Dict({"image": spaces.Box(0.0, 1.0, (R, R, 1), np.float32), "voltage": spaces.Box(-1.0, 1.0, (1,), np.float32)})
+    conn = DeviceFrameStackingConnector(spaces.Dict({"plunger_0": pl, "barrier_0": ba}), None, stacker=fs,
+                                        source=lambda: (feed["obs"], feed["reset"]))
+    assert conn.observation_space["plunger_0"]["image"].shape == (F, R, R, 2) and conn.observation_space["barrier_0"] is ba
+    hist = []
+    for t in range(T):
+        obs = {"plunger_images": torch.as_tensor(rng.random((B, N, R, R, 2)).astype(np.float32)),
+               "barrier_images": torch.as_tensor(rng.random((B, N - 1, R, R, 1)).astype(np.float32)),
+               "obs_gate_voltages": torch.as_tensor(rng.uniform(-1, 1, (B, N)).astype(np.float32)),
+               "obs_barrier_voltages": torch.as_tensor(rng.uniform(-1, 1, (B, N - 1)).astype(np.float32))}
+        feed["obs"] = obs; feed["reset"] = torch.tensor([t == 0, t == 0 or t == 2])      # env 1 starts a new episode at t = 2
+        hist.append(obs)
+        batch = conn(rl_module=None, batch={}, episodes=[], explore=True, shared_data={})
+    p = batch["obs"]["plunger_policy"]; b = batch["obs"]["barrier_policy"]
+    assert p["image"].shape == (B * N, F, R, R, 2) and b["image"].shape == (B * (N - 1), R, R, 1) and b["voltage"].shape == (B * (N - 1), 1)
+    for env, start in ((0, 0), (1, 2)):
+        for i in range(N):
+            lst = [{"image": hist[t]["plunger_images"][env, i].numpy(), "voltage": hist[t]["obs_gate_voltages"][env, i:i + 1].numpy()}
+                   for t in range(start, T)]
+            ref = O.frame_stack_env_to_module(lst, F)
+            k = env * N + i
+            assert np.array_equal(p["image"][k].numpy(), ref["image"]) and np.array_equal(p["voltage"][k].numpy(), ref["voltage"])
+            assert np.array_equal(p["attention_mask"][k].numpy(), ref["attention_mask"])
+    assert torch.equal(b["image"][1 * (N - 1) + 1], hist[-1]["barrier_images"][1, 1])
