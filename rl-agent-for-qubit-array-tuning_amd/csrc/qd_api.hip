@@ -22,7 +22,8 @@ struct qd_handle {
     float *gimg, *pimg, *bimg, *volt;
     unsigned long long* tel; int tel_words;
     unsigned long long* tstats;             // tile-search counters (validate mode)
-    int tile_search;                        // 1: tile-shared candidate search + exact redo pass; 0: per-pixel search only
+    int tile_search;                        // 0: per-pixel kernels only; 1: tile-shared candidate search + qd_k_ground; 2: fused tile kernel
+    unsigned char* redo;                    // [chunk][C][P] pixels the fused tile kernel hands to the per-pixel kernels
     unsigned long long obs_serial;
     char err[512];
 };
@@ -138,7 +139,11 @@ extern "C" int qd_create(const qd_config* cfg, int device, qd_handle** out) {
         QD_HIP(hipMalloc(&h->occ, sizeof(double) * (size_t)h->B * h->C * h->P * h->N));
     // the tile-shared search pays off where neighbouring pixels are close in voltage (fine grids) and needs >= 32
     // candidates valid across a tile (N >= 4); otherwise every pixel is searched on its own
-    h->tile_search = (h->N >= 4 && h->R >= 32 && !(cfg->flags & QD_FLAG_PIXEL_SEARCH)) ? 1 : 0;
+    h->tile_search = (h->N >= 4 && h->R >= 32 && !(cfg->flags & QD_FLAG_PIXEL_SEARCH)) ? ((cfg->flags & QD_FLAG_TILE_UNFUSED) ? 1 : 2) : 0;
+    if (h->tile_search == 2) {
+        QD_HIP(hipMalloc(&h->redo, (size_t)h->recs_envs * h->C * h->P));
+        QD_HIP(hipMemset(h->redo, 0, (size_t)h->recs_envs * h->C * h->P));
+    }
     if (cfg->flags & QD_FLAG_VALIDATE) {
         QD_HIP(hipMalloc(&h->tstats, sizeof(unsigned long long) * 16));
         QD_HIP(hipMemset(h->tstats, 0, sizeof(unsigned long long) * 16));
@@ -170,7 +175,7 @@ extern "C" int qd_create(const qd_config* cfg, int device, qd_handle** out) {
 extern "C" int qd_destroy(qd_handle* h) {
     if (!h) return QD_ERR_ARG;
     QdDeviceGuard guard_(h->device);
-    void* bufs[] = {h->params, h->state, h->steps, h->zraw, h->plohi, h->recs, h->occ, h->tel, h->eig, h->tstats};
+    void* bufs[] = {h->params, h->state, h->steps, h->zraw, h->plohi, h->recs, h->occ, h->tel, h->eig, h->tstats, h->redo};
     for (void* b : bufs) if (b) (void)hipFree(b);
     delete h;
     return QD_OK;
@@ -267,35 +272,67 @@ static QdNoiseCfg qd_noise_cfg(const qd_handle* h) {
     return nz;
 }
 
-// a5/a8/a9/a10 for `cnt` envs starting at list position `base`: tile-shared search + exact redo pass, or the
-// per-pixel search alone
-static int qd_launch_candidates(qd_handle* h, const int32_t* env_ids, int base, int cnt, hipStream_t s) {
-    const size_t shm = (size_t)QD_K * QD_CAND_BLOCK * (sizeof(double) + sizeof(uint16_t));
-    const int sorted = (h->cfg.flags & QD_FLAG_VALIDATE) ? 1 : 0;
-    dim3 g1(qd_cand_blocks(h->R), h->C, cnt);
-    if (h->tile_search) {
-        const int tiles = ((h->R + 7) / 8) * ((h->R + 7) / 8);
-        dim3 gt(tiles, h->C, cnt);
-        QD_DISPATCH_N(h->N, qd_k_tile_candidates<NN><<<gt, dim3(64), 0, s>>>(env_ids, base, h->R, h->params, h->state, h->recs,
-                                                                               sorted, h->cfg.noise_flags, h->tstats));
-        QD_HIP(hipGetLastError());
+static int qd_launch_ground(qd_handle* h, const int32_t* env_ids, int base, int cnt, hipStream_t s, const unsigned char* redo) {
+    dim3 g2((h->P + QD_GS_PPB - 1) / QD_GS_PPB, h->C, cnt);
+    if (h->eig) {
+        QD_DISPATCH_N(h->N, qd_k_ground<NN, true><<<g2, dim3(QD_GS_BLOCK), 0, s>>>(env_ids, base, h->R,
+                                                h->params, h->recs, h->zraw, h->occ, h->state, h->cfg.noise_flags, h->eig, redo));
+    } else {
+        QD_DISPATCH_N(h->N, qd_k_ground<NN, false><<<g2, dim3(QD_GS_BLOCK), 0, s>>>(env_ids, base, h->R,
+                                                h->params, h->recs, h->zraw, h->occ, h->state, h->cfg.noise_flags, nullptr, redo));
     }
-    QD_DISPATCH_N(h->N, qd_k_candidates<NN><<<g1, dim3(QD_CAND_BLOCK), shm, s>>>(env_ids, base, h->R, h->params, h->state, h->recs,
-                                                                                  sorted, h->cfg.noise_flags, h->tile_search));
     QD_HIP(hipGetLastError());
     return QD_OK;
 }
 
-static int qd_launch_ground(qd_handle* h, const int32_t* env_ids, int base, int cnt, hipStream_t s) {
-    dim3 g2((h->P + QD_GS_PPB - 1) / QD_GS_PPB, h->C, cnt);
-    if (h->eig) {
-        QD_DISPATCH_N(h->N, qd_k_ground<NN, true><<<g2, dim3(QD_GS_BLOCK), 0, s>>>(env_ids, base, h->R,
-                                                h->params, h->recs, h->zraw, h->occ, h->state, h->cfg.noise_flags, h->eig));
-    } else {
-        QD_DISPATCH_N(h->N, qd_k_ground<NN, false><<<g2, dim3(QD_GS_BLOCK), 0, s>>>(env_ids, base, h->R,
-                                                h->params, h->recs, h->zraw, h->occ, h->state, h->cfg.noise_flags, nullptr));
+#define QD_DISPATCH_TILE(N_, ...)                                                 \
+    switch (N_) {                                                                 \
+        case 4: { constexpr int NN = 4; __VA_ARGS__; } break;                            \
+        case 5: { constexpr int NN = 5; __VA_ARGS__; } break;                            \
+        case 6: { constexpr int NN = 6; __VA_ARGS__; } break;                            \
+        case 7: { constexpr int NN = 7; __VA_ARGS__; } break;                            \
+        case 8: { constexpr int NN = 8; __VA_ARGS__; } break;                            \
+        default: return qd_fail(h, QD_ERR_ARG, "tile kernels need n_dot in 4..8");      \
     }
-    QD_HIP(hipGetLastError());
+
+// a5-a13 for `cnt` envs starting at list position `base`.
+//   tile_search 2: fused tile kernel (search + ground state, one wave per 8x8 tile), then the per-pixel kernels on the
+//                  pixels it handed over;  1: tile search + exact redo pass, then qd_k_ground;  0: per-pixel kernels.
+static int qd_launch_csd(qd_handle* h, const int32_t* env_ids, int base, int cnt, hipStream_t s, int what /*1 cand, 2 ground, 3 both*/) {
+    const size_t shm = (size_t)QD_K * QD_CAND_BLOCK * (sizeof(double) + sizeof(uint16_t));
+    const int sorted = (h->cfg.flags & QD_FLAG_VALIDATE) ? 1 : 0;
+    dim3 g1(qd_cand_blocks(h->R), h->C, cnt);
+    const int tiles = ((h->R + 7) / 8) * ((h->R + 7) / 8);
+    dim3 gt(tiles, h->C, cnt);
+    if (h->tile_search == 2) {
+        if (what & 1) {
+            if (sorted) {
+                QD_DISPATCH_TILE(h->N, qd_k_tile<NN, 1, true><<<gt, dim3(64), 0, s>>>(env_ids, base, h->R, h->params, h->state, h->recs,
+                                 1, h->cfg.noise_flags, h->tstats, h->zraw, h->occ, h->eig, h->redo));
+            } else {
+                QD_DISPATCH_TILE(h->N, qd_k_tile<NN, 1, false><<<gt, dim3(64), 0, s>>>(env_ids, base, h->R, h->params, h->state, nullptr,
+                                 0, h->cfg.noise_flags, nullptr, h->zraw, h->occ, nullptr, h->redo));
+            }
+            QD_HIP(hipGetLastError());
+            QD_DISPATCH_N(h->N, qd_k_candidates<NN><<<g1, dim3(QD_CAND_BLOCK), shm, s>>>(env_ids, base, h->R, h->params, h->state, h->recs,
+                                                                                          sorted, h->cfg.noise_flags, 2, h->redo));
+            QD_HIP(hipGetLastError());
+            int rc = qd_launch_ground(h, env_ids, base, cnt, s, h->redo);
+            if (rc) return rc;
+        }
+        return QD_OK;
+    }
+    if (what & 1) {
+        if (h->tile_search == 1) {
+            QD_DISPATCH_TILE(h->N, qd_k_tile<NN, 0, false><<<gt, dim3(64), 0, s>>>(env_ids, base, h->R, h->params, h->state, h->recs,
+                             sorted, h->cfg.noise_flags, h->tstats, nullptr, nullptr, nullptr, nullptr));
+            QD_HIP(hipGetLastError());
+        }
+        QD_DISPATCH_N(h->N, qd_k_candidates<NN><<<g1, dim3(QD_CAND_BLOCK), shm, s>>>(env_ids, base, h->R, h->params, h->state, h->recs,
+                                                                                      sorted, h->cfg.noise_flags, h->tile_search, nullptr));
+        QD_HIP(hipGetLastError());
+    }
+    if (what & 2) return qd_launch_ground(h, env_ids, base, cnt, s, nullptr);
     return QD_OK;
 }
 
@@ -315,9 +352,7 @@ extern "C" int qd_observe(qd_handle* h, const int32_t* env_ids, int n, void* str
     }
     for (int base = 0; base < n; base += h->chunk) {
         const int cnt = (n - base < h->chunk) ? n - base : h->chunk;
-        int rc = qd_launch_candidates(h, env_ids, base, cnt, s);
-        if (rc) return rc;
-        rc = qd_launch_ground(h, env_ids, base, cnt, s);
+        int rc = qd_launch_csd(h, env_ids, base, cnt, s, 3);
         if (rc) return rc;
     }
     if (h->cfg.noise_flags & QD_NOISE_LATCH) {
@@ -462,7 +497,7 @@ extern "C" int qd_time_ground_kernel(qd_handle* h, int iters, float* mean_ms, vo
     if (!ev.ok) return qd_fail(h, QD_ERR_HIP, "hipEventCreate");
     const int cnt = h->chunk < h->B ? h->chunk : h->B;
     QD_HIP(hipEventRecord(ev.a, s));
-    for (int i = 0; i < iters; ++i) { int rc = qd_launch_ground(h, nullptr, 0, cnt, s); if (rc) return rc; }
+    for (int i = 0; i < iters; ++i) { int rc = qd_launch_csd(h, nullptr, 0, cnt, s, 2); if (rc) return rc; }
     QD_HIP(hipEventRecord(ev.b, s));
     QD_HIP(hipEventSynchronize(ev.b));
     float ms = 0.f;
@@ -479,7 +514,7 @@ extern "C" int qd_time_candidates_kernel(qd_handle* h, int iters, float* mean_ms
     if (!ev.ok) return qd_fail(h, QD_ERR_HIP, "hipEventCreate");
     const int cnt = h->chunk < h->B ? h->chunk : h->B;
     QD_HIP(hipEventRecord(ev.a, s));
-    for (int i = 0; i < iters; ++i) { int rc = qd_launch_candidates(h, nullptr, 0, cnt, s); if (rc) return rc; }
+    for (int i = 0; i < iters; ++i) { int rc = qd_launch_csd(h, nullptr, 0, cnt, s, 1); if (rc) return rc; }
     QD_HIP(hipEventRecord(ev.b, s));
     QD_HIP(hipEventSynchronize(ev.b));
     float ms = 0.f;

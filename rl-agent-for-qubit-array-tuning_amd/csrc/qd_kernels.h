@@ -171,7 +171,7 @@ template <int N>
 __global__ void __launch_bounds__(QD_CAND_BLOCK, QD_CAND_WAVES)
 qd_k_candidates(const int* __restrict__ env_ids, int env_base, int R, const double* __restrict__ params,
                 const double* __restrict__ state, QdPixelRec* __restrict__ recs, int sort_output, int noise_flags,
-                int only_flagged) {
+                int only_flagged, const unsigned char* __restrict__ redo_flags) {
     constexpr int G = N + 1, NB = N - 1, V = 2 * N;
     const QdLayout L = qd_layout(N);
     const int slot = blockIdx.z;
@@ -199,7 +199,8 @@ qd_k_candidates(const int* __restrict__ env_ids, int env_base, int R, const doub
     if (qd_radial_replaced(spar, sst, L, ch, noise_flags)) return;   // image will be pure noise: nothing to solve
     QdPixelRec* rec = recs + ((size_t)slot * (N - 1) + ch) * P + p;
     // second pass behind the tile search (qd_tile.h): only the pixels it left to the exact per-pixel search
-    if (only_flagged && rec->nvalid != QD_T_REDO) return;
+    if (only_flagged == 1 && rec->nvalid != QD_T_REDO) return;
+    if (only_flagged == 2 && !redo_flags[((size_t)slot * (N - 1) + ch) * P + p]) return;
     double vd[N], ncont[N], isa;
     {
         double v_ext[V], vpp[G], tc[NB];
@@ -254,7 +255,8 @@ template <int N, bool VALIDATE = false>
 __global__ void __launch_bounds__(QD_GS_BLOCK, QD_GS_WAVES)
 qd_k_ground(const int* __restrict__ env_ids, int env_base, int R, const double* __restrict__ params,
             const QdPixelRec* __restrict__ recs, double* __restrict__ zraw, double* __restrict__ occ_out,
-            const double* __restrict__ state, int noise_flags, double* __restrict__ eig_out = nullptr) {
+            const double* __restrict__ state, int noise_flags, double* __restrict__ eig_out = nullptr,
+            const unsigned char* __restrict__ redo_flags = nullptr) {
     constexpr int G = N + 1;
     const QdLayout L = qd_layout(N);
     const int slot = blockIdx.z;
@@ -277,11 +279,18 @@ qd_k_ground(const int* __restrict__ env_ids, int env_base, int R, const double* 
         const int pc = p < P ? p : P - 1;
         if (p0 + it * 8 >= P) break;                         // uniform for the block
         const QdPixelRec* rec = rbase + pc;
+        // behind the fused tile kernel only the pixels it handed over are solved here (both halves of a wave run in
+        // lock step: the wave skips when neither of its two pixels is flagged, results are written per pixel)
+        bool mine = true;
+        if (redo_flags) {
+            mine = p < P && redo_flags[((size_t)slot * (N - 1) + ch) * P + pc] != 0;
+            if (!__any(mine)) continue;
+        }
         double occ, lam, resid = 0.0;
         qd_ground_pixel<N, VALIDATE>(rec, W, &occ, &lam, &resid);
         if constexpr (VALIDATE) {
             // [B][C][P][2]: ground energy of the kept-state Hamiltonian and the relative residual of the eigenpair
-            if (eig_out && (threadIdx.x & 31) == 0 && p < P) {
+            if (eig_out && (threadIdx.x & 31) == 0 && p < P && mine) {
                 double* eo = eig_out + (((size_t)e * (N - 1) + ch) * P + p) * 2;
                 eo[0] = lam; eo[1] = resid;
             }
@@ -297,13 +306,13 @@ qd_k_ground(const int* __restrict__ env_ids, int env_base, int R, const double* 
             b += __shfl_xor(b, 4, 32);
             b += __shfl_xor(b, 8, 32);
             b += __shfl_xor(b, 16, 32);
-            if (m == 0 && p < P) {
+            if (m == 0 && p < P && mine) {
                 const double vs = pvv[N];
                 const double Ns = rint(vs);                             // np.round: half to even
                 const double a = par[L.cdd_inv + N * G + N];
                 zraw[((size_t)e * (N - 1) + ch) * P + p] = 2.0 * b + a * (2.0 * (Ns - vs) + 1.0);
             }
-            if (occ_out && (m & 3) == 0 && i < N && p < P)
+            if (occ_out && (m & 3) == 0 && i < N && p < P && mine)
                 occ_out[(((size_t)e * (N - 1) + ch) * P + p) * N + i] = occ;
         }
     }

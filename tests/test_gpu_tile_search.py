@@ -36,10 +36,28 @@ def test_tile_search_equals_pixel_search(N, R, mode):
     (tile, pix), st = _pair(B, N, R, 4000 + N, mode, rng)
     ct = tile.candidates(); cp = pix.candidates()
     assert np.array_equal(ct, cp), (N, R, mode, int((ct != cp).any(axis=(3, 4)).sum()))
-    # identical records -> identical ground states and images
-    assert np.array_equal(tile.raw()[0], pix.raw()[0])
-    assert np.array_equal(tile.global_image.cpu().numpy(), pix.global_image.cpu().numpy())
+    # same kept states -> same Hamiltonians: the fused kernel's ground state (one pixel per lane, energies from the tile
+    # planes) against the per-pixel kernel's (canonical energies).  Eigenvalues agree to round-off of ||H|| and both
+    # eigenpairs have round-off residuals in every pixel and regime; occupations / signal agree wherever the gap of the
+    # two lowest eigenvalues lets float64 resolve the ground vector.
+    et = tile.eigen(); ep = pix.eigen()
+    assert et[..., 1].max() <= 1e-11, et[..., 1].max()          # (the per-pixel kernel reaches ~1e-8 in the wild regime)
+    assert ep[..., 1].max() <= 1e-6, ep[..., 1].max()
+    ot = tile.occupations(); op = pix.occupations(); rt = tile.raw()[0]; rp = pix.raw()[0]
+    worst = 0.0
+    for e in range(B):
+        dev = H.dev_view(N, tile._params_host[e]); sv = H.state_view(N, st[e])
+        for ch in range(N - 1):
+            sp = H.pixel_spectrum(dev, sv.vgm, dev.origin, sv.gate_v, sv.sensor_gt, sv.barrier_v, dev.window, ch, R, states=cp[e, ch])
+            assert np.all(np.abs(et[e, ch, :, 0] - ep[e, ch, :, 0]) <= 1e-12 * sp["hnorm"]), (e, ch)
+            d = np.abs(ot[e, ch] - op[e, ch]).max(axis=1)
+            assert np.all(sp["rel_gap"][d > 1e-7] <= H.GAP_MIN), (e, ch, d.max())
+            ok = sp["rel_gap"] > H.GAP_MIN
+            if ok.any():
+                worst = max(worst, d[ok].max())
+                assert np.allclose(rt[e, ch][ok], rp[e, ch][ok], rtol=1e-7, atol=1e-9), (e, ch)
     s = tile.search_stats()
+    print(f"[fused vs per-pixel] N={N} R={R} {mode}: max occupation difference over resolvable pixels {worst:.2e}")
     print(f"[tile search] N={N} R={R} {mode}: {s}")
     assert s["tiles"] > 0 and s["tiles_redone"] < 0.5 * s["tiles"], s         # the fast path did the work
     tile.close(); pix.close()
