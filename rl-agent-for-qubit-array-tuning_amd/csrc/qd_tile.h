@@ -617,7 +617,7 @@ qd_k_tile(const int* __restrict__ env_ids, int env_base, int R, const double* __
         QdTileGroundLds& Gd = GdH.g;
         QdTileGroundVec& Vv = *reinterpret_cast<QdTileGroundVec*>(&T.u);
         double occ[N], lam = 0.0, resid = 0.0;
-        const bool ok = qd_tile_ground<N, VALIDATE>(T, Gd, Vv, nS, nSfront, lo_, KM, alive, xs, ys, isa, emin, Ecg * isa, tc, occ, lam, resid);
+        const bool ok = qd_tile_ground<N, VALIDATE>(T, Gd, Vv, nS, nSfront, lo_, KM, alive, xs, ys, isa, emin, Ecg * isa, tc, occ, lam, resid, stats);
         if (stats && lane == 0 && !ok) { atomicAdd(&stats[1], 1ull); atomicAdd(&stats[8 + 6], 1ull); }
         if (!inside) return;
         const bool give_up = !ok || !alive;

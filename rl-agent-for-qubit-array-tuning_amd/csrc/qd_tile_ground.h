@@ -389,7 +389,8 @@ __device__ __forceinline__ void qd_tile_solve(const QdTileGroundLds& Gd, QdTileG
 template <int N, bool VALIDATE>
 __device__ bool qd_tile_ground(const QdTileLds& T, QdTileGroundLds& Gd, QdTileGroundVec& Vv, int nS, int nSfront, const int* lo_,
                                const QdMask256& KM, bool alive, double xs, double ys, double isa, double emin, double eshift,
-                               const double* tcv, double (&occ)[N], double& lam_best, double& resid_best) {
+                               const double* tcv, double (&occ)[N], double& lam_best, double& resid_best,
+                               unsigned long long* stats = nullptr) {
     constexpr int NB = N - 1, M = QD_T_NMAXC;
     const int lane = threadIdx.x;
     // couplings: per lane in LDS (gathered by uniform pair index in the matvec); pairs that do not couple at all
@@ -523,6 +524,7 @@ __device__ bool qd_tile_ground(const QdTileLds& T, QdTileGroundLds& Gd, QdTileGr
         const bool solve = has && (n > 1) && (lbc <= ub);
         double lam = INFINITY, resid = 0.0;
         double x[M];
+        if (stats && lane == 0) { atomicAdd(&stats[5], 1ull); if (n > 1) atomicAdd(&stats[6], 1ull); if (n > 1 && __any(solve)) atomicAdd(&stats[7], 1ull); }
         if (n > 1 && __any(solve)) {
             qd_tile_solve<N, VALIDATE>(Gd, Vv, n, solve, F, lam, x, resid);
         } else {

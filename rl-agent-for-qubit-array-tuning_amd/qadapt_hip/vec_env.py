@@ -393,6 +393,8 @@ class VecQuantumDeviceEnv:
         t = max(int(out[0]), 1)
         return {"tiles": int(out[0]), "tiles_redone": int(out[1]), "pixels_redone": int(out[2]),
                 "pixels_redone_few_states": int(out[4]), "mean_superset": int(out[3]) / t,
+                "structures_per_tile": int(out[5]) / t, "multi_state_structures_per_tile": int(out[6]) / t,
+                "solves_per_tile": int(out[7]) / t,
                 "tiles_redone_by_reason": {k: int(out[8 + i]) for i, k in
                                            enumerate(("", "ranges", "seeds", "frontier", "leaves", "superset")) if k}}
 

@@ -49,7 +49,8 @@ def test_tile_search_equals_pixel_search(N, R, mode):
         dev = H.dev_view(N, tile._params_host[e]); sv = H.state_view(N, st[e])
         for ch in range(N - 1):
             sp = H.pixel_spectrum(dev, sv.vgm, dev.origin, sv.gate_v, sv.sensor_gt, sv.barrier_v, dev.window, ch, R, states=cp[e, ch])
-            assert np.all(np.abs(et[e, ch, :, 0] - ep[e, ch, :, 0]) <= 1e-12 * sp["hnorm"]), (e, ch)
+            assert np.all(np.abs(et[e, ch, :, 0] - sp["lam0"]) <= 1e-12 * sp["hnorm"]), (e, ch)     # fused vs the oracle's dense eigh
+            assert np.all(np.abs(ep[e, ch, :, 0] - sp["lam0"]) <= 1e-10 * sp["hnorm"]), (e, ch)     # (per-pixel kernel: ~3e-12 in the wild regime)
             d = np.abs(ot[e, ch] - op[e, ch]).max(axis=1)
             assert np.all(sp["rel_gap"][d > 1e-7] <= H.GAP_MIN), (e, ch, d.max())
             ok = sp["rel_gap"] > H.GAP_MIN
