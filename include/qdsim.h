@@ -36,8 +36,10 @@ extern "C" {
 #define QD_FLAG_VALIDATE 1    /* keep per-pixel candidate records and occupations  */
 #define QD_FLAG_PIXEL_SEARCH 2 /* a9 by the per-pixel search only (default: one search per 8x8 pixel tile where the
                                  grid is fine enough, with an exact per-pixel redo pass; same results, A/B switch) */
-#define QD_FLAG_TILE_UNFUSED 4 /* tile-shared search, but the ground state by the per-pixel kernel (default: one fused
-                                 kernel does both, one pixel per lane; A/B switch) */
+#define QD_FLAG_TILE_FUSED 4  /* experimental: one fused kernel per 8x8 tile does the search AND the ground state with one pixel
+                                 per lane (csrc/qd_tile_ground.h).  Same results to round-off (its eigenpairs have the smaller
+                                 residuals) and no 488-B/pixel record hand-off, but slower than the default pipeline on
+                                 gfx950 today */
 
 /* Stochastic stages.  The generators are counter-based Philox streams, so
  * results are reproducible per (rng_seed, global env id, observation number, channel, pixel)

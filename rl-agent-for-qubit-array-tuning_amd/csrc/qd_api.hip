@@ -139,7 +139,7 @@ extern "C" int qd_create(const qd_config* cfg, int device, qd_handle** out) {
         QD_HIP(hipMalloc(&h->occ, sizeof(double) * (size_t)h->B * h->C * h->P * h->N));
     // the tile-shared search pays off where neighbouring pixels are close in voltage (fine grids) and needs >= 32
     // candidates valid across a tile (N >= 4); otherwise every pixel is searched on its own
-    h->tile_search = (h->N >= 4 && h->R >= 32 && !(cfg->flags & QD_FLAG_PIXEL_SEARCH)) ? ((cfg->flags & QD_FLAG_TILE_UNFUSED) ? 1 : 2) : 0;
+    h->tile_search = (h->N >= 4 && h->R >= 32 && !(cfg->flags & QD_FLAG_PIXEL_SEARCH)) ? ((cfg->flags & QD_FLAG_TILE_FUSED) ? 2 : 1) : 0;
     if (h->tile_search == 2) {
         QD_HIP(hipMalloc(&h->redo, (size_t)h->recs_envs * h->C * h->P));
         QD_HIP(hipMemset(h->redo, 0, (size_t)h->recs_envs * h->C * h->P));

@@ -617,6 +617,10 @@ qd_k_tile(const int* __restrict__ env_ids, int env_base, int R, const double* __
         QdTileGroundLds& Gd = GdH.g;
         QdTileGroundVec& Vv = *reinterpret_cast<QdTileGroundVec*>(&T.u);
         double occ[N], lam = 0.0, resid = 0.0;
+#if defined(QD_TILE_ABLATE) && QD_TILE_ABLATE == 1
+        if (inside) { redo_flags[pix_index] = 0; zraw[((size_t)e * (N - 1) + ch) * P + p] = emin; }   // diagnostic: search only
+        return;
+#endif
         const bool ok = qd_tile_ground<N, VALIDATE>(T, Gd, Vv, nS, nSfront, lo_, KM, alive, xs, ys, isa, emin, Ecg * isa, tc, occ, lam, resid, stats);
         if (stats && lane == 0 && !ok) { atomicAdd(&stats[1], 1ull); atomicAdd(&stats[8 + 6], 1ull); }
         if (!inside) return;

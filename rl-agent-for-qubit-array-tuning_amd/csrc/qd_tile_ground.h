@@ -80,7 +80,6 @@ __device__ __forceinline__ int qd_s_logical(int phys, int nSfront) { return phys
 
 struct QdTileGroundLds {
     uint32_t nbw[QD_T_SCAP][4];        // hop table of S: byte 2d = forward partner over pair (d, d+1), 2d+1 = backward; 255 = none
-    float rb[QD_T_SCAP];               // sum of the sqrt factors over ALL partners in S (loose Gershgorin radius per unit coupling)
     int mS[16];                        // members of the current structure (indices into S, ascending)
     int ecnt[16];                      // directed edges per row
     unsigned char ej[QD_T_NMAXC][16], ed[QD_T_NMAXC][16];
@@ -93,13 +92,12 @@ struct QdTileGroundVec { double q[QD_T_NMAXC][64]; double tl[QD_MAXN][64]; };
 // Build the hop table of S (once per tile).  codes: nibble N-1-i = c_i - lo_i.  pairnz: bit d set iff the pair (d, d+1)
 // couples (t_d != 0; zero couplings do not link states, so tc = 0 stays exactly diagonal).
 template <int N>
-__device__ __forceinline__ void qd_tile_hop_table(const QdTileLds& T, QdTileGroundLds& Gd, int nS, int nSfront, const int* lo_, unsigned pairnz) {
+__device__ __forceinline__ void qd_tile_hop_table(const QdTileLds& T, QdTileGroundLds& Gd, int nS, int nSfront, unsigned pairnz) {
     const int lane = threadIdx.x;
     for (int base = 0; base < nS; base += 64) {
         const int j = base + lane;
         const uint32_t cj = j < nS ? T.scode[qd_s_phys(j, nSfront)] : 0u;
         uint32_t row[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-        float rbsum = 0.f;
         for (int k = 0; k < nS; ++k) {
             const uint32_t ck = T.scode[qd_s_phys(k, nSfront)];              // uniform
             const uint32_t Z = ((ck | 0x88888888u) - cj) ^ 0x88888888u;    // nibble 0: equal, 1: +1, 0xF: -1 (digits < 8)
@@ -110,27 +108,29 @@ __device__ __forceinline__ void qd_tile_hop_table(const QdTileLds& T, QdTileGrou
                 const int qn = tz >> 2;                                      // nibble of dot d+1
                 const int d = N - 2 - qn;
                 if (d >= 0 && ((pairnz >> d) & 1u)) {
-                    const int cd = (int)((cj >> (4 * (qn + 1))) & 15u), cd1 = (int)((cj >> (4 * qn)) & 15u);
-                    int lod = 0, lod1 = 0;
-#pragma unroll
-                    for (int i = 0; i < N; ++i) { if (i == d) lod = lo_[i]; if (i == d + 1) lod1 = lo_[i]; }
-                    const int nd = cd + lod, nd1 = cd1 + lod1;
-                    const int prod = fwd ? nd * (nd1 + 1) : nd1 * (nd + 1);
                     const int slot = 2 * d + (fwd ? 0 : 1);
                     const uint32_t sh = 8u * (unsigned)(slot & 3);
 #pragma unroll
                     for (int w = 0; w < 4; ++w) if (w == (slot >> 2)) row[w] = (row[w] & ~(0xFFu << sh)) | ((uint32_t)k << sh);
-                    rbsum += sqrtf((float)prod) * 1.000001f;
                 }
             }
         }
         if (j < nS) {
 #pragma unroll
             for (int w = 0; w < 4; ++w) Gd.nbw[j][w] = row[w];
-            Gd.rb[j] = rbsum;
         }
     }
     __builtin_amdgcn_wave_barrier();
+}
+
+// occupation product of the hop in `slot` (2d forward: electron d -> d+1, 2d+1 backward) for the state with tile code `code`:
+// H_ij = -t_d sqrt(n_from (n_to + 1)) with the occupations of the ROW state (hamiltonian_build.py:125-131)
+template <int N>
+__device__ __forceinline__ int qd_tile_hop_product(uint32_t code, int slot, const int* lo_) {
+    const int d = slot >> 1;                                  // slot is a compile-time constant at every call site
+    const int qn = N - 2 - d;                                 // nibble of dot d+1
+    const int nd = (int)((code >> (4 * (qn + 1))) & 15u) + lo_[d], nd1 = (int)((code >> (4 * qn)) & 15u) + lo_[d + 1];
+    return (slot & 1) ? nd1 * (nd + 1) : nd * (nd1 + 1);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -191,10 +191,10 @@ __device__ __forceinline__ void qd_tile_lanczos(const QdTileGroundLds& Gd, QdTil
         qd_tile_matvec<M>(Gd, Vv, n, F, q, w);
         double a = 0.0;
 #pragma unroll
-        for (int i = 0; i < M; ++i) a = fma(q[i], w[i], a);
+        for (int i = 0; i < M; ++i) if (i < n) a = fma(q[i], w[i], a);
         double b2 = 0.0;
 #pragma unroll
-        for (int i = 0; i < M; ++i) { w[i] = w[i] - a * q[i] - bp * qp[i]; b2 = fma(w[i], w[i], b2); }
+        for (int i = 0; i < M; ++i) if (i < n) { w[i] = w[i] - a * q[i] - bp * qp[i]; b2 = fma(w[i], w[i], b2); }
         double b = 0.0, ib = 0.0;
         if (b2 > 0.0) qd_sqrt_rsqrt(b2, b, ib);
         if (!done) {
@@ -210,13 +210,13 @@ __device__ __forceinline__ void qd_tile_lanczos(const QdTileGroundLds& Gd, QdTil
 #pragma unroll
                 for (int r = 0; r < M; ++r) if (r == j) yj = y[r];
 #pragma unroll
-                for (int i = 0; i < M; ++i) x[i] = fma(yj, q[i], x[i]);
+                for (int i = 0; i < M; ++i) if (i < n) x[i] = fma(yj, q[i], x[i]);
                 last = j + 1 >= k;
             }
             if (last) done = true;
             else {
 #pragma unroll
-                for (int i = 0; i < M; ++i) { qp[i] = q[i]; q[i] = w[i] * ib; }
+                for (int i = 0; i < M; ++i) if (i < n) { qp[i] = q[i]; q[i] = w[i] * ib; }
                 bp = b;
             }
         }
@@ -240,6 +240,9 @@ __device__ __forceinline__ void qd_tile_solve(const QdTileGroundLds& Gd, QdTileG
     for (int i = 0; i < M; ++i) { al[i] = 0.0; be[i] = 0.0; y[i] = 0.0; x[i] = 0.0; }
     qd_tile_lanczos<M, 1>(Gd, Vv, n, solve, F, al, be, k, y, x);
     if (!solve) al[0] = F[0];
+#if defined(QD_TILE_ABLATE) && QD_TILE_ABLATE == 4
+    lam_out = al[0]; resid_out = 0.0; x[0] = 1.0; return;         // diagnostic: Lanczos pass 1 only
+#endif
     // ---- lowest eigenvalue of T: Laguerre from the left (as qd_groundstate.h 6a) ----
     double lo = INFINITY, hi = INFINITY, bmax = 0.0;
 #pragma unroll
@@ -263,6 +266,7 @@ __device__ __forceinline__ void qd_tile_solve(const QdTileGroundLds& Gd, QdTileG
             double p0 = 1.0, p1 = 1.0, d0 = 0.0, d1 = 0.0, e0 = 0.0, e1 = 0.0, bprev = 0.0;
 #pragma unroll
             for (int i = 0; i < M; ++i) {
+                if (i >= n) break;
                 if (i < k) {
                     const double a_ = al[i] - xl;
                     const double b2_ = bprev * bprev;
@@ -307,6 +311,9 @@ __device__ __forceinline__ void qd_tile_solve(const QdTileGroundLds& Gd, QdTileG
         }
     }
     const double lam = (k <= 1) ? al[0] : xl;
+#if defined(QD_TILE_ABLATE) && QD_TILE_ABLATE == 5
+    lam_out = lam; resid_out = 0.0; x[0] = 1.0; return;           // diagnostic: + Laguerre
+#endif
     // ---- eigenvector of T: inverse iteration on (T - sigma) = L D L^T, sigma just below lam ----
     {
         const double sig = (k <= 1) ? lam : xl - 2e-16 * tscale;
@@ -354,6 +361,9 @@ __device__ __forceinline__ void qd_tile_solve(const QdTileGroundLds& Gd, QdTileG
             for (int i = 0; i < M; ++i) y[i] = y[i] * inv;
         }
     }
+#if defined(QD_TILE_ABLATE) && QD_TILE_ABLATE == 6
+    lam_out = lam; resid_out = 0.0; x[0] = y[0]; return;          // diagnostic: + inverse iteration
+#endif
     // ---- Lanczos pass 2: x = sum_j y_j q_j ----
     qd_tile_lanczos<M, 2>(Gd, Vv, n, solve, F, al, be, k, y, x);
     if (solve) {
@@ -394,28 +404,54 @@ __device__ bool qd_tile_ground(const QdTileLds& T, QdTileGroundLds& Gd, QdTileGr
     constexpr int NB = N - 1, M = QD_T_NMAXC;
     const int lane = threadIdx.x;
     // couplings: per lane in LDS (gathered by uniform pair index in the matvec); pairs that do not couple at all
-    double tmax = 0.0;
     unsigned pz = 0;
 #pragma unroll
-    for (int d = 0; d < NB; ++d) { Vv.tl[d][lane] = tcv[d]; tmax = fmax(tmax, fabs(tcv[d])); pz |= (tcv[d] != 0.0 ? 1u : 0u) << d; }
+    for (int d = 0; d < NB; ++d) { Vv.tl[d][lane] = tcv[d]; pz |= (tcv[d] != 0.0 ? 1u : 0u) << d; }
     unsigned pairnz = 0;
 #pragma unroll
     for (int d = 0; d < NB; ++d) pairnz |= (__any(alive && ((pz >> d) & 1u)) ? 1u : 0u) << d;
-    qd_tile_hop_table<N>(T, Gd, nS, nSfront, lo_, pairnz);
+    qd_tile_hop_table<N>(T, Gd, nS, nSfront, pairnz);
 
-    // states that can sit in a ground-candidate component: loose Gershgorin bound against the lowest diagonal entry
+    // States that can sit in a ground-candidate component: the state's own Gershgorin disc (kept partners only, my
+    // couplings; the sqrt factors rounded up) must reach below my lowest diagonal entry.  By Gershgorin's theorem the
+    // component that holds my ground state contains such a state, so every other component is never looked at.
     const double ub0 = emin * isa;
     QdMask256 cand; cand.w[0] = cand.w[1] = cand.w[2] = cand.w[3] = 0ull;
     double seedlb = INFINITY; int seed0 = 0;
     for (int s = 0; s < nS; ++s) {
-        if (qd_m_test(KM, s)) {
-            const int ph = qd_s_phys(s, nSfront);
-            const double e = fma(xs, T.sa[ph], fma(ys, T.sb[ph], T.sD[ph])) * isa;
-            const double lb = e - tmax * (double)Gd.rb[s];
+        const bool kept = qd_m_test(KM, s);
+        if (!__any(kept)) continue;
+        const int ph = qd_s_phys(s, nSfront);
+        const double e = fma(xs, T.sa[ph], fma(ys, T.sb[ph], T.sD[ph])) * isa;
+        const uint32_t cs = (uint32_t)qd_uni_i((int)T.scode[ph]);
+        double rad = 0.0;
+#pragma unroll
+        for (int wv = 0; wv < (2 * NB + 3) / 4; ++wv) {
+            const uint32_t rw = (uint32_t)qd_uni_i((int)Gd.nbw[s][wv]);
+#pragma unroll
+            for (int bq = 0; bq < 4; ++bq) {
+                if (wv * 4 + bq < 2 * NB) {
+                    const int kk = (int)((rw >> (8 * bq)) & 255u);
+                    if (kk != 255) {
+                        const float sq = sqrtf((float)qd_tile_hop_product<N>(cs, wv * 4 + bq, lo_)) * 1.000001f;
+                        const double td = fabs(tcv[(wv * 4 + bq) >> 1]);
+                        rad = fma(qd_m_test(KM, kk) ? td : 0.0, (double)sq, rad);
+                    }
+                }
+            }
+        }
+        if (kept) {
+            const double lb = e - rad;
             if (lb <= ub0) qd_m_set(cand, s);
             if (lb < seedlb) { seedlb = lb; seed0 = s; }
         }
     }
+#if defined(QD_TILE_ABLATE) && QD_TILE_ABLATE == 2
+#pragma unroll
+    for (int i = 0; i < N; ++i) occ[i] = seedlb;              // diagnostic: hop table + candidate discs only
+    lam_best = 0.0; resid_best = 0.0;
+    return true;
+#endif
     QdMask256 resolved; resolved.w[0] = resolved.w[1] = resolved.w[2] = resolved.w[3] = 0ull;
     double ub = ub0;                                        // upper bound of my ground energy
     lam_best = INFINITY; resid_best = 0.0;
@@ -484,17 +520,12 @@ __device__ bool qd_tile_ground(const QdTileLds& T, QdTileGroundLds& Gd, QdTileGr
                 for (int slot = 0; slot < 2 * NB; ++slot) {
                     const int kk = (int)((Gd.nbw[s][slot >> 2] >> (8 * (slot & 3))) & 255u);
                     if (kk != 255 && qd_m_test(Mm, kk)) {
-                        const int d = slot >> 1;
-                        const int qn = N - 2 - d;                                       // nibble of dot d+1
-                        const int cd = (int)((cj >> (4 * (qn + 1))) & 15u), cd1 = (int)((cj >> (4 * qn)) & 15u);
-                        int lod = 0, lod1 = 0;
-#pragma unroll
-                        for (int i = 0; i < N; ++i) { if (i == d) lod = lo_[i]; if (i == d + 1) lod1 = lo_[i]; }
-                        const int nd = cd + lod, nd1 = cd1 + lod1;
-                        const int prod = (slot & 1) ? nd1 * (nd + 1) : nd * (nd1 + 1);
+                        const int prod = qd_tile_hop_product<N>(cj, slot, lo_);
+                        double sq_ = 0.0, rs_ = 0.0;
+                        if (prod > 0) qd_sqrt_rsqrt((double)prod, sq_, rs_);
                         Gd.ej[lane][cnt] = (unsigned char)qd_m_rank(Mm, kk);
-                        Gd.ed[lane][cnt] = (unsigned char)d;
-                        Gd.esq[lane][cnt] = sqrt((double)prod);
+                        Gd.ed[lane][cnt] = (unsigned char)(slot >> 1);
+                        Gd.esq[lane][cnt] = sq_;
                         cnt++;
                     }
                 }
@@ -525,7 +556,11 @@ __device__ bool qd_tile_ground(const QdTileLds& T, QdTileGroundLds& Gd, QdTileGr
         double lam = INFINITY, resid = 0.0;
         double x[M];
         if (stats && lane == 0) { atomicAdd(&stats[5], 1ull); if (n > 1) atomicAdd(&stats[6], 1ull); if (n > 1 && __any(solve)) atomicAdd(&stats[7], 1ull); }
+#if defined(QD_TILE_ABLATE) && QD_TILE_ABLATE == 3
+        if (false) {                                           // diagnostic: structure loop without the solves
+#else
         if (n > 1 && __any(solve)) {
+#endif
             qd_tile_solve<N, VALIDATE>(Gd, Vv, n, solve, F, lam, x, resid);
         } else {
 #pragma unroll
@@ -554,16 +589,6 @@ __device__ bool qd_tile_ground(const QdTileLds& T, QdTileGroundLds& Gd, QdTileGr
         if (has) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) resolved.w[k] |= Mm.w[k];
-        }
-        if (first) {
-            // an eigenvalue is known now: states whose loose bound lies above it cannot be in a ground component
-            for (int s = 0; s < nS; ++s) {
-                if (qd_m_test(cand, s)) {
-                    const int ph = qd_s_phys(s, nSfront);
-                    const double e = fma(xs, T.sa[ph], fma(ys, T.sb[ph], T.sD[ph])) * isa;
-                    if (e - tmax * (double)Gd.rb[s] > ub) qd_m_clear(cand, s);
-                }
-            }
         }
         first = false;
     }

@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("QDSIM_LIB", os.path.join(CSRC, "libqdsim.so"))   # QD
 
 QD_FLAG_VALIDATE = 1
 QD_FLAG_PIXEL_SEARCH = 2
-QD_FLAG_TILE_UNFUSED = 4
+QD_FLAG_TILE_FUSED = 4
 QD_NOISE_SENSOR = 1
 QD_NOISE_RADIAL = 2
 QD_NOISE_LATCH = 4

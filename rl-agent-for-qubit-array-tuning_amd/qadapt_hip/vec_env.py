@@ -48,8 +48,9 @@ class VecQuantumDeviceEnv:
                  resolution=None, device=None, seed=None, env_id_offset=0, capacitance_model=None,
                  validate=False, env_chunk=0, reset_kalman_on_reset=False, noise=None,
                  vary_peak_width=False, peak_width_alpha=0.01, voltage_capacitance_model=None, pixel_search=False,
-                 unfused=False):
+                 fused=False):
         """pixel_search: a9 by the per-pixel search only (A/B switch; the default runs one search per 8x8 tile).
+        fused: experimental fused tile kernel (search + ground state, one pixel per lane; QD_FLAG_TILE_FUSED).
         seed: base seed of the per-env device streams (PCG64(seed + global env id)) and the Philox key of
         the stochastic stages; None draws fresh OS entropy, as the reference's unseeded generators do
         (qarray_base_class.py:773-774, env.py:161).
@@ -116,7 +117,7 @@ class VecQuantumDeviceEnv:
         cfg = _lib.QdConfig(struct_size=ctypes.sizeof(_lib.QdConfig), n_dot=N, resolution=R, batch=B,
                             max_steps=self.max_steps, env_chunk=int(env_chunk),
                             flags=(_lib.QD_FLAG_VALIDATE if validate else 0) | (_lib.QD_FLAG_PIXEL_SEARCH if pixel_search else 0)
-                            | (_lib.QD_FLAG_TILE_UNFUSED if unfused else 0), noise_flags=self._noise_flags(noise),
+                            | (_lib.QD_FLAG_TILE_FUSED if fused else 0), noise_flags=self._noise_flags(noise),
                             gate_ramp_start=float(rew["gate_ramp_start"]),
                             gate_quadratic_start=float(rew["gate_quadratic_start"]),
                             barrier_ramp_start=float(rew["barrier_ramp_start"]),

@@ -10,11 +10,11 @@ import helpers as H
 pytestmark = pytest.mark.gpu
 
 
-def _pair(B, N, R, seed, mode, rng):
+def _pair(B, N, R, seed, mode, rng, fused=False):
     from qadapt_hip.vec_env import VecQuantumDeviceEnv, SyntheticCapacitanceModel
     envs = []
     for px in (False, True):
-        env = VecQuantumDeviceEnv(B, num_dots=N, resolution=R, seed=seed, validate=True, pixel_search=px,
+        env = VecQuantumDeviceEnv(B, num_dots=N, resolution=R, seed=seed, validate=True, pixel_search=px, fused=fused and not px,
                                   capacitance_model=SyntheticCapacitanceModel(7))
         env.reset()
         envs.append(env)
@@ -30,10 +30,13 @@ def _pair(B, N, R, seed, mode, rng):
 
 @pytest.mark.parametrize("N,R,mode", [(8, 64, "start"), (8, 64, "mid"), (8, 64, "near"), (6, 64, "mid"), (5, 44, "near"),
                                        (4, 64, "start"), (4, 64, "near"), (4, 36, "mid"), (7, 33, "start"), (8, 100, "near")])
-def test_tile_search_equals_pixel_search(N, R, mode):
+@pytest.mark.parametrize("fused", [False, True])
+def test_tile_search_equals_pixel_search(N, R, mode, fused):
+    """fused=False: the default pipeline (tile search + per-pixel ground-state kernel); fused=True: the experimental fused
+    tile kernel (ground state with one pixel per lane)."""
     B = 2 if R <= 64 else 1
     rng = np.random.default_rng(31 * N + R)
-    (tile, pix), st = _pair(B, N, R, 4000 + N, mode, rng)
+    (tile, pix), st = _pair(B, N, R, 4000 + N, mode, rng, fused=fused)
     ct = tile.candidates(); cp = pix.candidates()
     assert np.array_equal(ct, cp), (N, R, mode, int((ct != cp).any(axis=(3, 4)).sum()))
     # same kept states -> same Hamiltonians: the fused kernel's ground state (one pixel per lane, energies from the tile
@@ -41,19 +44,25 @@ def test_tile_search_equals_pixel_search(N, R, mode):
     # eigenpairs have round-off residuals in every pixel and regime; occupations / signal agree wherever the gap of the
     # two lowest eigenvalues lets float64 resolve the ground vector.
     et = tile.eigen(); ep = pix.eigen()
-    assert et[..., 1].max() <= 1e-11, et[..., 1].max()          # (the per-pixel kernel reaches ~1e-8 in the wild regime)
-    assert ep[..., 1].max() <= 1e-6, ep[..., 1].max()
+    if fused:
+        assert et[..., 1].max() <= 1e-9, et[..., 1].max()       # (tiles the fused kernel hands over are solved by the per-pixel kernel)
+    else:
+        assert np.array_equal(tile.raw()[0], pix.raw()[0])      # identical records -> identical ground states
+    assert ep[..., 1].max() <= 1e-6, ep[..., 1].max()           # (the per-pixel kernel reaches ~3e-8 at 64x64 in the wild regime)
     ot = tile.occupations(); op = pix.occupations(); rt = tile.raw()[0]; rp = pix.raw()[0]
     worst = 0.0
     for e in range(B):
         dev = H.dev_view(N, tile._params_host[e]); sv = H.state_view(N, st[e])
         for ch in range(N - 1):
             sp = H.pixel_spectrum(dev, sv.vgm, dev.origin, sv.gate_v, sv.sensor_gt, sv.barrier_v, dev.window, ch, R, states=cp[e, ch])
-            assert np.all(np.abs(et[e, ch, :, 0] - sp["lam0"]) <= 1e-12 * sp["hnorm"]), (e, ch)     # fused vs the oracle's dense eigh
+            assert np.all(np.abs(et[e, ch, :, 0] - sp["lam0"]) <= (1e-12 if fused else 1e-10) * sp["hnorm"]), (e, ch)   # vs the oracle's dense eigh
             assert np.all(np.abs(ep[e, ch, :, 0] - sp["lam0"]) <= 1e-10 * sp["hnorm"]), (e, ch)     # (per-pixel kernel: ~3e-12 in the wild regime)
             d = np.abs(ot[e, ch] - op[e, ch]).max(axis=1)
-            assert np.all(sp["rel_gap"][d > 1e-7] <= H.GAP_MIN), (e, ch, d.max())
-            ok = sp["rel_gap"] > H.GAP_MIN
+            # (the per-pixel kernel's eigenpairs carry residuals up to ~1e-8 in the wild regime, so the two solvers are
+            # compared where the gap is 100x wider than the oracle comparison needs)
+            gap_min = 100 * H.GAP_MIN if fused else H.GAP_MIN
+            assert np.all(sp["rel_gap"][d > 1e-7] <= gap_min), (e, ch, d.max())
+            ok = sp["rel_gap"] > gap_min
             if ok.any():
                 worst = max(worst, d[ok].max())
                 assert np.allclose(rt[e, ch][ok], rp[e, ch][ok], rtol=1e-7, atol=1e-9), (e, ch)
