@@ -1,11 +1,11 @@
 """Summarise rocprofv3 --pmc passes: one line per (pass, kernel, counter) with the mean value per dispatch.
 
-    python scripts/pmc_summary.py gpurun_out/pmc > profiles/rNN_pmc_summary.csv
+    python scripts/pmc_summary.py gpurun_out/<tag>/pmc > gpurun_out/<tag>/pmc_summary.csv
 
 Each pass is a sub-directory of the argument holding rocprofv3's *_counter_collection.csv
-(`rocprofv3 --pmc A B C -d gpurun_out/pmc/<pass> --output-format csv -- python scripts/kbench.py ...`).
-FETCH_SIZE / WRITE_SIZE are KiB per dispatch; on gfx950 FETCH_SIZE under-reports wide reads by 2x
-(MI355X_MICROARCH.md, HBM section)."""
+(`rocprofv3 --pmc A B C -d <dir>/<pass> --output-format csv -- python3 scripts/kbench.py ...`, one counter set per run,
+no trace options combined).  FETCH_SIZE / WRITE_SIZE are KiB per dispatch; on gfx950 FETCH_SIZE under-reports wide
+reads by 2x (MI355X_MICROARCH.md, HBM section).  Kernel names contain commas: the kernel column is quoted."""
 import csv, glob, os, re, sys
 from collections import defaultdict
 
@@ -18,7 +18,8 @@ for path in sorted(glob.glob(os.path.join(root, "**", "*counter_collection.csv")
             k = re.sub(r"\(.*", "", row["Kernel_Name"]).strip()
             a = acc[(pas, k, row["Counter_Name"])]
             a[0] += float(row["Counter_Value"]); a[1] += 1
-print("pass,kernel,counter,dispatches,mean_per_dispatch")
+w = csv.writer(sys.stdout)
+w.writerow(["pass", "kernel", "counter", "dispatches", "mean_per_dispatch"])
 for (pas, k, c), (s, n) in sorted(acc.items()):
     if k.startswith("void qd_k") or k.startswith("qd_k"):
-        print(f"{pas},{k},{c},{n},{s / n}")
+        w.writerow([pas, k, c, n, s / n])
