@@ -23,7 +23,7 @@
 
 #if defined(__HIPCC__)
 
-#define QD_T_FCAP 512          // frontier capacity (partial states per level; 2 x 512 x 12 B of LDS)
+#define QD_T_FCAP 512          // frontier capacity (partial states per level; 2 x 512 x 12 B of LDS; 832 was tried: the tiles it saves fail on the superset size instead)
 #define QD_T_SCAP 255          // superset capacity (state indices are bytes, 255 = none)
 #define QD_T_REDO (-1)         // QdPixelRec.nvalid marker: pixel left to the exact per-pixel search
 

@@ -13,7 +13,7 @@ python bench.py --config mixed --envs 1024 --steps 10 --warmup 3 --no-cpu-baseli
 python bench.py --gpus 2 --share-gpu --backend gloo --envs 1024 --steps 6 --warmup 2 > $out/bench_2ranks_rehearsal_one_gpu.json 2> /dev/null || echo "2-rank failed"
 rocprofv3 --kernel-trace --stats -d $out/kstats --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > $out/kstats.log 2>&1 || echo "kstats failed"
 cp $out/kstats/*/*kernel_stats.csv $out/kernel_stats_bench_headline.csv 2>/dev/null
-i=0
+mkdir -p $out/pmc; i=0
 for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_ANY" \
            "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_WAVE_CYCLES SQ_BUSY_CYCLES" \
            "SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
