@@ -615,3 +615,39 @@ def test_randomised_scene_sweep(seed):
             checked += int(ok.sum())
     assert checked > 0 or mode == "start"          # random start voltages can be wild in every pixel
     env.close()
+
+
+def test_config2_shape_in_product_mode_against_oracle():
+    """BASELINE config 2 exactly (4-dot, 256 envs, 64x64) on the BENCHED path (no validate flag: unsorted records, chunked
+    launches, tile search with redo pass): raw sensor signal and normalised images of a few envs against the C oracle."""
+    import torch
+    from qadapt_hip.vec_env import VecQuantumDeviceEnv, SyntheticCapacitanceModel
+    N, R, B = 4, 64, 256
+    env = VecQuantumDeviceEnv(B, num_dots=N, resolution=R, seed=1234, capacitance_model=SyntheticCapacitanceModel(99), env_chunk=100)
+    env.reset()
+    st, steps = env.get_state()
+    rng = np.random.default_rng(2)
+    picks = [0, 99, 100, 255]                                  # chunk boundaries included
+    for e in picks:
+        st[e] = H.place(N, st[e], ("near", "mid", "near", "mid")[picks.index(e)], rng)
+    env.set_state(st, steps)
+    env.observe()
+    raw, plohi = env.raw()
+    img = env.global_image.cpu().numpy()
+    worst = 0.0
+    for e in picks:
+        dev = H.dev_view(N, env._params_host[e]); sv = H.state_view(N, st[e])
+        z, occ = OC.env_images(dev, sv.vgm, dev.origin, sv.gate_v, sv.sensor_gt, sv.barrier_v, dev.window, R, want_occ=True)
+        all_ok = True
+        for ch in range(N - 1):
+            sp = H.pixel_spectrum(dev, sv.vgm, dev.origin, sv.gate_v, sv.sensor_gt, sv.barrier_v, dev.window, ch, R)
+            ok = sp["rel_gap"] > H.GAP_MIN
+            d = np.abs(raw[e, ch] - z[ch]) / np.maximum(np.abs(z[ch]), 1e-3)
+            assert np.all(sp["rel_gap"][d > 1e-6] <= H.GAP_MIN), (e, ch, d[ok].max())
+            worst = max(worst, d[ok].max()); all_ok &= bool(ok.all())
+        assert plohi[e, 0] == np.percentile(raw[e], 0.5) and plohi[e, 1] == np.percentile(raw[e], 99.5)
+        if all_ok:
+            full = O.normalise_image(z.reshape(N - 1, R, R).transpose(1, 2, 0))
+            assert np.abs(full - img[e]).max() <= 2e-6, (e, np.abs(full - img[e]).max())
+    print(f"[parity, product mode] config-2 shape: max relative signal error over resolvable pixels {worst:.2e}")
+    env.close()
