@@ -45,7 +45,7 @@ def test_tile_search_equals_pixel_search(N, R, mode, fused):
     # two lowest eigenvalues lets float64 resolve the ground vector.
     et = tile.eigen(); ep = pix.eigen()
     if fused:
-        assert et[..., 1].max() <= 1e-9, et[..., 1].max()       # (tiles the fused kernel hands over are solved by the per-pixel kernel)
+        assert et[..., 1].max() <= 1e-6, et[..., 1].max()       # (tiles the fused kernel hands over are solved by the per-pixel kernel)
     else:
         assert np.array_equal(tile.raw()[0], pix.raw()[0])      # identical records -> identical ground states
     assert ep[..., 1].max() <= 1e-6, ep[..., 1].max()           # (the per-pixel kernel reaches ~3e-8 at 64x64 in the wild regime)
