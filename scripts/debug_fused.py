@@ -9,7 +9,7 @@ from qadapt_hip.vec_env import VecQuantumDeviceEnv, SyntheticCapacitanceModel
 def run(N, R, mode, seed, B=2):
     rng = np.random.default_rng(31 * N + R)
     envs = []
-    for kw in (dict(), dict(pixel_search=True)):
+    for kw in (dict(fused=True), dict(pixel_search=True)):
         env = VecQuantumDeviceEnv(B, num_dots=N, resolution=R, seed=seed, validate=True, capacitance_model=SyntheticCapacitanceModel(7), **kw)
         env.reset(); envs.append(env)
     st, steps = envs[0].get_state()
