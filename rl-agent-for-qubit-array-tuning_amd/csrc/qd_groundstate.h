@@ -357,6 +357,9 @@ __device__ void qd_ground_pixel(const QdPixelRec* __restrict__ rec, QdWaveLds& W
     }
     const double tscale = fmax(fmax(fabs(lo), fabs(hi)), qd_seg_max((r < k - 1) ? fabs(be_mine) : 0.0, MB, ssz, buf, hb));
     double xl = lo - (1e-3 * tscale + 1e-300);
+#if defined(QD_DEBUG_STATS)
+    int dbg_myits = 0, dbg_waveits = 0;                    // diagnostic build (scripts/solver_stats.py)
+#endif
     {
 #if defined(QD_ABLATE) && QD_ABLATE == 1
         bool conv = true;                                  // diagnostic: skip Laguerre
@@ -368,6 +371,9 @@ __device__ void qd_ground_pixel(const QdPixelRec* __restrict__ rec, QdWaveLds& W
         double sprev = 0.0;                                // previous Laguerre step (0: none yet)
         for (int it = 0; it < 48; ++it) {
             if (!__any(!conv)) break;
+#if defined(QD_DEBUG_STATS)
+            dbg_waveits = it + 1; if (!conv) dbg_myits = it + 1;
+#endif
             // p, p', p'' at xl: three-term recurrences over the rows of T.  The first 8 rows use the
             // register-resident member slots (no bit scanning); magnitudes are rescaled every 4 rows.
             double p0 = 1.0, p1 = 1.0, d0 = 0.0, d1 = 0.0, e0 = 0.0, e1 = 0.0, bprev = 0.0;
@@ -617,6 +623,13 @@ __device__ void qd_ground_pixel(const QdPixelRec* __restrict__ rec, QdWaveLds& W
         const double r2 = qd_half_sum(rr * rr);
         const double hn = -qd_half_min(-(fabs(Fabs) + radius));       // ||H||_inf over the 32 states (unshifted)
         *resid_out = sqrt(r2) / (hn > 0.0 ? hn : 1.0);
+#if defined(QD_DEBUG_STATS)
+        // diagnostic build (-DQD_DEBUG_STATS, scripts/solver_stats.py): the residual slot carries packed solver statistics instead:
+        // Laguerre iterations of the wave + 1e2 * those of the winning component + 1e4 * rows of the wave + 1e6 * rows of the
+        // winner + 1e8 * lanes in solved components + 1e10 * largest solved component
+        *resid_out = (double)dbg_waveits + 1e2 * (double)__shfl(dbg_myits, wroot, 32) + 1e4 * (double)kmax + 1e6 * (double)__shfl(k, wroot, 32)
+                   + 1e8 * (double)__popc(qd_half_ballot(solve)) + 1e10 * (double)-qd_half_min(solve ? -(double)ssz : 0.0);
+#endif
     }
     // <n_i> = sum_m p_m n_m[i] for all dots at once by a reduce-scatter butterfly: each exchange halves
     // the number of partial sums a lane carries (4 + 2 + 1 exchanges), two more finish the single sum

@@ -18,10 +18,26 @@ env.reset()
 st0, steps = env.get_state()
 rng = np.random.default_rng(0)
 for mode in a.modes.split(","):
-    st = st0.copy()
-    for e in range(a.envs):
-        st[e] = H.place(a.dots, st0[e], mode, rng, vgm_noise=0.0)
-    env.set_state(st, steps)
+    if mode.startswith("wild"):
+        # the bench's regime: envs reset, then stepped with uniform random actions for e % K + 1 steps (staggered phases)
+        K = int(mode[4:] or 12)
+        env.set_state(st0, steps)
+        gen = torch.Generator(device="cpu").manual_seed(7)
+        act = torch.rand((K, a.envs, 2 * a.dots - 1), generator=gen) * 2 - 1
+        phase = torch.arange(a.envs) % K
+        for t in range(K):
+            act_t = act[t].clone(); act_t[phase < t] = 0.0          # envs past their phase hold still (zero deltas are not a no-op for absolute actions, so:)
+            stb, sb = env.get_state()
+            env.step(act_t.cuda())
+            sta, sa = env.get_state()
+            hold = (phase < t).numpy()
+            sta[hold] = stb[hold]
+            env.set_state(sta, sb)
+    else:
+        st = st0.copy()
+        for e in range(a.envs):
+            st[e] = H.place(a.dots, st0[e], mode, rng, vgm_noise=0.0)
+        env.set_state(st, steps)
     c = env.time_candidates_kernel(a.iters); g = env.time_ground_kernel(a.iters)
     px = a.envs * (a.dots - 1) * a.resolution ** 2
     print(f"{mode:6s} N={a.dots} B={a.envs}: candidates {c:8.3f} ms ({c*1e6/px:6.2f} ns/px)  ground {g:8.3f} ms ({g*1e6/px:6.2f} ns/px)"
