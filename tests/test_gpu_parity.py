@@ -558,7 +558,7 @@ def test_nan_inputs_give_zero_image_not_a_hang():
 
 @pytest.mark.parametrize("N,R,B,chunk", [(4, 16, 5, 2), (8, 8, 7, 3)])
 def test_chunked_launches_are_bit_identical_to_one_launch(N, R, B, chunk):
-    """The hot kernels run over `env_chunk` envs per launch (a 4096-env batch is 54 launches): the
+    """The hot kernels run over `env_chunk` envs per launch (a 4096-env batch is 4 launches with the default 16-GiB record budget, 54 with 1 GiB): the
     chunking -- including a ragged last chunk and a partial reset through an env-id list -- must not
     change a single bit of any output.  (Validate mode keeps every env's records and therefore
     always runs one launch, so both handles are product-mode ones; validate vs product is a different
