@@ -25,6 +25,7 @@ st, _ = env.get_state()
 env.observe()
 cand = env.candidates(); occ = env.occupations(); raw, _ = env.raw(); eig = env.eigen()
 tot = dict(px=0, mism=0, unres=0, wocc=0.0, wsig=0.0, wres=0.0, wresok=0.0, wlam=0.0)
+dec = {}     # unresolvable pixels by decade of rel_gap: [count, count with |occ - oracle| > 1e-3, > 1e-6]
 t0 = time.time()
 for e in range(B):
     dev = H.dev_view(N, env._params_host[e]); sv = H.state_view(N, st[e])
@@ -36,6 +37,9 @@ for e in range(B):
         ok = sp["rel_gap"] > H.GAP_MIN
         u += int((~ok).sum()); tcm = max(tcm, sp["tcmax"].max())
         wr = max(wr, eig[e, ch, :, 1].max()); wl = max(wl, (np.abs(eig[e, ch, :, 0] - sp["lam0"]) / sp["hnorm"]).max())
+        dd = np.abs(occ[e, ch] - ref["occ"]).max(axis=1)
+        for g, x in zip(np.floor(np.log10(np.maximum(sp["rel_gap"][~ok], 1e-20))).astype(int), dd[~ok]):
+            c = dec.setdefault(int(g), [0, 0, 0]); c[0] += 1; c[1] += x > 1e-3; c[2] += x > 1e-6
         if ok.any():
             wo = max(wo, np.abs(occ[e, ch] - ref["occ"]).max(axis=1)[ok].max())
             wrk = max(wrk, eig[e, ch, :, 1][ok].max())
@@ -47,4 +51,6 @@ for e in range(B):
 print(f"TOTAL {N}-dot {R}x{R}, {B} envs after {steps} random-action steps: {tot['px']} pixels, {tot['mism']} state-list mismatches, "
       f"{tot['unres']} unresolvable in float64 (rel_gap <= {H.GAP_MIN}), max |occ-oracle| {tot['wocc']:.2e}, max rel signal err {tot['wsig']:.2e}, "
       f"max eigen residual {tot['wres']:.2e} (resolvable pixels {tot['wresok']:.2e}), max |lam-lam_oracle|/|H| {tot['wlam']:.2e}; search stats {env.search_stats()}; oracle time {time.time()-t0:.0f}s")
+print("unresolvable pixels by decade of rel_gap (10^d): count, |occ-oracle| > 1e-3, > 1e-6")
+for g in sorted(dec): print(f"  1e{g:+d}: {dec[g][0]:7d} {dec[g][1]:7d} {dec[g][2]:7d}")
 env.close()
