@@ -194,16 +194,24 @@ __device__ void qd_ground_pixel(const QdPixelRec* __restrict__ rec, QdWaveLds& W
     unsigned tcq = 0;                                     // bit 4q set iff pair N-2-q couples
 #pragma unroll
     for (int q = 0; q < N - 1; ++q) tcq |= ((tcnz >> (N - 2 - q)) & 1u) << (4 * q);
+    // The relation is symmetric, so every pair is tested once: in round j lane m tests its partner (m + j) mod 32 and hands the
+    // verdict to that partner as well (which receives it from lane (m - j) mod 32) -- 16 rounds instead of 32 tests per lane.
     unsigned nbrmask = 0;
 #pragma unroll 4
-    for (int j = 0; j < 32; ++j) {
-        const unsigned cj = __shfl(ecode, j, 32);
+    for (int j = 1; j <= 16; ++j) {
+        const int pj = (m + j) & 31;
+        const unsigned cj = __shfl(ecode, pj, 32);
         const unsigned Z = ((cj | 0x88888888u) - ecode) ^ 0x88888888u;
         const int tz = __builtin_ctz(Z | 0x80000000u);     // Z == 0 (same state): tz = 31, Zs = 0, no hop (a nibble of Z is never 8)
         const unsigned Zs = Z >> tz;
         // branch-free on purpose (bitwise, not short-circuit): the compiler otherwise builds a divergent branch per j
         const unsigned hop = ((unsigned)(Zs == 0x1Fu) | (unsigned)(Zs == 0xF1u)) & (tcq >> tz) & 1u;
-        nbrmask |= hop << j;
+        nbrmask |= hop << pj;
+        if (j < 16) {                                      // (round 16 pairs m with m + 16 from both sides already)
+            const int qj = (m - j) & 31;
+            const unsigned back = (unsigned)__shfl((int)hop, qj, 32);
+            nbrmask |= back << qj;
+        }
     }
     // states beyond the valid count (|0..0> padding) neither hop nor are hopped to
     nbrmask = valid ? (nbrmask & (nvalid >= 32 ? 0xFFFFFFFFu : ((1u << nvalid) - 1u))) : 0u;
@@ -282,7 +290,7 @@ __device__ void qd_ground_pixel(const QdPixelRec* __restrict__ rec, QdWaveLds& W
 #pragma unroll
     for (int i = 0; i < QD_NBREG; ++i) radius += fabs(nbc[i]);
     for (int s = QD_NBREG; s < maxcnt; ++s) radius += fabs(W.coef[s - QD_NBREG][lane]);
-    const double upper_all = qd_half_min(F);
+    const double upper_all = 0.0;                          // = min F: the diagonal is relative to the lowest free energy
     const double comp_lower = qd_seg_min(F - radius, MB, ssz, buf, hb);
     const bool active = comp_lower <= upper_all;
 
@@ -298,7 +306,7 @@ __device__ void qd_ground_pixel(const QdPixelRec* __restrict__ rec, QdWaveLds& W
     double al_mine = F, be_mine = 0.0, ib_mine = 0.0;      // singleton: T = [F]
     int k = solve ? 0 : 1;
     bool done = !solve;
-    const int jmax = qd_wave_max_int(solve ? ssz : 0);
+    const int jmax = smax;                                 // (loop bound only: the loops stop when no lane is running)
     for (int j = 0; j < jmax; ++j) {
         if (!__any(!done)) break;
         // matvec: q is published once and every neighbour's entry is one 64-bit LDS read (a 64-bit
@@ -337,7 +345,7 @@ __device__ void qd_ground_pixel(const QdPixelRec* __restrict__ rec, QdWaveLds& W
     __builtin_amdgcn_wave_barrier();
     qd_lds_cvptr al = (qd_lds_cvptr)W.al;
     qd_lds_cvptr be = (qd_lds_cvptr)W.be;
-    const int kmax = qd_wave_max_int(k);
+    const int kmax = smax;                                 // k <= component size: bound of the row loops beyond the 8 unrolled rows
 
     // ---- 6a. lowest eigenvalue of T: Laguerre iteration from the left ----------
     // p(x) = det(T - x) has only real roots; started left of all of them, Laguerre's
@@ -353,9 +361,11 @@ __device__ void qd_ground_pixel(const QdPixelRec* __restrict__ rec, QdWaveLds& W
         const double bme = (r < k - 1) ? be_mine : 0.0;
         const double g = (r < k) ? al_mine - fabs(bprev) - fabs(bme) : INFINITY;
         lo = qd_seg_min(g, MB, ssz, buf, hb);                       // Gershgorin lower bound
-        hi = qd_seg_min((r < k) ? al_mine : INFINITY, MB, ssz, buf, hb);
+        hi = lo;
     }
-    const double tscale = fmax(fmax(fabs(lo), fabs(hi)), qd_seg_max((r < k - 1) ? fabs(be_mine) : 0.0, MB, ssz, buf, hb));
+    // scale of T: ||T|| <= max_j (|alpha_j| + 2 beta_j) <= 3 anorm (the maximum Lanczos kept; component-uniform) -- two more
+    // segment reductions (min alpha, max beta) would buy nothing
+    const double tscale = fmax(fabs(lo), 3.0 * anorm);
     double xl = lo - (1e-3 * tscale + 1e-300);
 #if defined(QD_DEBUG_STATS)
     int dbg_myits = 0, dbg_waveits = 0;                    // diagnostic build (scripts/solver_stats.py)
@@ -368,6 +378,10 @@ __device__ void qd_ground_pixel(const QdPixelRec* __restrict__ rec, QdWaveLds& W
 #endif
         const double dk = (double)k;
         const bool huge_scale = __any(tscale > 1e30);
+        // |alpha_j|, beta_j <= anorm (Lanczos kept the maximum), |xl| <= 3.01 anorm: a minor grows by less than a factor
+        // 5 anorm per row and shrinks by no more than ~anorm, so eight rows from p_0 = 1 stay inside the double range
+        // without any rescaling when 1e-10 < anorm < 1e30 (wave-uniform test; the tail loop rescales on its own)
+        const bool rescale8 = __any(solve && !(anorm < 1e30 && anorm > 1e-10));
         double sprev = 0.0;                                // previous Laguerre step (0: none yet)
         for (int it = 0; it < 48; ++it) {
             if (!__any(!conv)) break;
@@ -424,7 +438,7 @@ __device__ void qd_ground_pixel(const QdPixelRec* __restrict__ rec, QdWaveLds& W
                 }
                 // eight rows grow the minors by at most (2 tscale)^8 from 1: one rescale at the end is enough
                 // unless the matrix scale itself is astronomic (wave-uniform test)
-                if (i == 7 || (i == 3 && huge_scale)) QD_LAG_RESCALE()
+                if ((i == 7 && (rescale8 || kmax > 8)) || (i == 3 && huge_scale)) QD_LAG_RESCALE()
             }
 #undef QD_LAG_ROW_PP
             {
@@ -474,6 +488,7 @@ __device__ void qd_ground_pixel(const QdPixelRec* __restrict__ rec, QdWaveLds& W
     lo = (k <= 1) ? lam : xl - 2e-16 * tscale;                          // shift for the inverse iteration
     hi = lam;
 
+    double yscale = 1.0;                                   // 1 / ||y|| of the last inverse iteration
     // ---- 6b. eigenvector of T: inverse iteration, SPD factorisation at sigma = lo
     // (T - lo) = L D L^T.  Every member lane runs the same serial recurrences and
     // writes identical values: rd[row i] = 1/d_i, lf[row i] = l_{i-1}, yv[row i] = y_i.
@@ -481,15 +496,18 @@ __device__ void qd_ground_pixel(const QdPixelRec* __restrict__ rec, QdWaveLds& W
     {
         const double sig = lo;
         const double tiny = 1e-300 + 1e-18 * fmax(fabs(lo), fabs(hi));
-        double d = 1.0, bprev = 0.0, rdp = 1.0;
+        // the factorisation sweep also does the forward substitution of the first iteration (right-hand side of ones)
+        double d = 1.0, bprev = 0.0, rdp = 1.0, zfac = 0.0;
 #define QD_FAC_ROW(SLOT, FIRST)                                                     \
         {                                                                           \
-            double di_ = al[SLOT] - sig;                                            \
-            if (!(FIRST)) { const double l_ = bprev * rdp; di_ = di_ - l_ * bprev; W.lf[SLOT] = l_; } \
+            double di_ = al[SLOT] - sig, z_ = 1.0;                                  \
+            if (!(FIRST)) { const double l_ = bprev * rdp; di_ = di_ - l_ * bprev; W.lf[SLOT] = l_; z_ = 1.0 - l_ * zfac; } \
             if (!(di_ > tiny)) di_ = tiny;                                          \
             d = di_;                                                                \
             rdp = qd_rcp(d);                                /* 1/d_i: stored, and reused as 1/d_{i-1} by the next row */ \
             W.rd[SLOT] = rdp;                                                       \
+            W.yv[SLOT] = z_ * rdp;                                                  \
+            zfac = z_;                                                              \
             bprev = be[SLOT];                                                       \
         }
 #pragma unroll
@@ -500,12 +518,15 @@ __device__ void qd_ground_pixel(const QdPixelRec* __restrict__ rec, QdWaveLds& W
         }
 #undef QD_FAC_ROW
         __builtin_amdgcn_wave_barrier();
+        // (the normalisation of y is not a sweep of its own: the 1/||y|| of the first iteration scales the right-hand side
+        // of the second, the one of the second scales y_j where pass 2 reads it)
         for (int iter = 0; iter < 2; ++iter) {
-            // forward  L z = rhs, then w = D^-1 z
+            // forward  L z = rhs, then w = D^-1 z   (second iteration only: the first was done with the factorisation)
+            if (iter > 0) {
             double zprev = 0.0;
 #define QD_FWD_ROW(SLOT, FIRST)                                                     \
             {                                                                       \
-                const double rhs_ = (iter == 0) ? 1.0 : W.yv[SLOT];                 \
+                const double rhs_ = W.yv[SLOT] * yscale;                            \
                 const double z_ = (FIRST) ? rhs_ : rhs_ - W.lf[SLOT] * zprev;       \
                 W.yv[SLOT] = z_ * W.rd[SLOT];                                       \
                 zprev = z_;                                                         \
@@ -518,6 +539,7 @@ __device__ void qd_ground_pixel(const QdPixelRec* __restrict__ rec, QdWaveLds& W
             }
 #undef QD_FWD_ROW
             __builtin_amdgcn_wave_barrier();
+            }
             // backward  L^T y = w : y_i = w_i - l_i y_{i+1}; rows k-1 .. 0
             double ynext = 0.0, lnext = 0.0, nrm = 0.0;
 #define QD_BWD_ROW(SLOT, IDX)                                                       \
@@ -540,13 +562,7 @@ __device__ void qd_ground_pixel(const QdPixelRec* __restrict__ rec, QdWaveLds& W
             __builtin_amdgcn_wave_barrier();
             double inv = 1.0, sn_ = 0.0;
             if (nrm > 0.0) qd_sqrt_rsqrt(nrm, sn_, inv);          // 1/sqrt by rsq + Newton (no correctly rounded norm needed)
-#pragma unroll
-            for (int i = 0; i < 8; ++i) if (i < k) W.yv[MB.idx[i]] = W.yv[MB.idx[i]] * inv;
-            {
-                unsigned mm = MB.rest;
-                for (int i = 8; i < kmax; ++i) if (i < k) { const int b = hb + __builtin_ctz(mm); mm &= mm - 1; W.yv[b] = W.yv[b] * inv; }
-            }
-            __builtin_amdgcn_wave_barrier();
+            yscale = inv;
         }
     }
 
@@ -565,7 +581,7 @@ __device__ void qd_ground_pixel(const QdPixelRec* __restrict__ rec, QdWaveLds& W
         for (int j = 0; j < jmax; ++j) {
             if (!__any(!done2)) break;
             double yj = 0.0, a = 0.0, b = 0.0, ib = 0.0;
-            if (!done2) { const int bb = __builtin_ctz(mm); mm &= mm - 1; yj = W.yv[hb + bb]; a = al[hb + bb]; b = be[hb + bb]; ib = W.ib[hb + bb]; }
+            if (!done2) { const int bb = __builtin_ctz(mm); mm &= mm - 1; yj = W.yv[hb + bb] * yscale; a = al[hb + bb]; b = be[hb + bb]; ib = W.ib[hb + bb]; }
             double w = F * q2;
             buf[lane] = q2;
             __builtin_amdgcn_wave_barrier();
