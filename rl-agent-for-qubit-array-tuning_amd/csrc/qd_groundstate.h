@@ -164,14 +164,14 @@ __device__ void qd_ground_pixel(const QdPixelRec* __restrict__ rec, QdWaveLds& W
     const int nvalid = rec->nvalid;
     const bool valid = m < nvalid;
     const unsigned code = valid ? (unsigned)rec->idx[m] : 0u;
-    int n[N];
-    unsigned ecode = 0;
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-        const int dig = (code >> (2 * (N - 1 - i))) & 3;
-        n[i] = valid ? W.pfl[hh][i] + dig - 1 : 0;
-        ecode |= (unsigned)dig << (4 * (N - 1 - i));
-    }
+    // digit of dot i (base 4, dot 0 most significant) -> nibble N-1-i of ecode: spread the 2-bit digits to 4-bit spacing
+    unsigned ecode = code;
+    ecode = (ecode | (ecode << 8)) & 0x00FF00FFu;
+    ecode = (ecode | (ecode << 4)) & 0x0F0F0F0Fu;
+    ecode = (ecode | (ecode << 2)) & 0x33333333u;
+    // occupation of dot i in this lane's state: floor + digit - 1 (0 for the padding lanes); decoded where it is needed,
+    // not kept in registers through the solve
+    auto occ_of = [&](int i) -> int { return valid ? (int)W.pfl[hh][i] + (int)((ecode >> (4 * (N - 1 - i))) & 3u) - 1 : 0; };
     // F_m: the candidate kernel already evaluated the canonical energy of every kept state, and of the
     // |0..0> padding when fewer than 32 candidates are valid (N <= 3)
     // The diagonal enters RELATIVE to the pixel's lowest free energy: H - c I has the same eigenvectors, and without the
@@ -237,9 +237,9 @@ __device__ void qd_ground_pixel(const QdPixelRec* __restrict__ rec, QdWaveLds& W
                 const unsigned ay = (unsigned)(Y < 0 ? -Y : Y);
                 const int q = __builtin_ctz(ay) >> 2;
                 const int d = N - 2 - q;                   // adjacent pair (d, d+1)
-                int nd = 0, nd1 = 0;
-#pragma unroll
-                for (int i = 0; i < N; ++i) { if (i == d) nd = n[i]; if (i == d + 1) nd1 = n[i]; }
+                // occupations of the pair's two dots straight from the code's digits and the floors in LDS
+                const int nd = (int)W.pfl[hh][d] + (int)((ecode >> (4 * (q + 1))) & 3u) - 1;
+                const int nd1 = (int)W.pfl[hh][d + 1] + (int)((ecode >> (4 * q)) & 3u) - 1;
                 const double t = pvv[9 + d];
                 // Y < 0: s_j = s_i - e_d + e_{d+1} (forward); else backward
                 const double prod = (Y < 0) ? (double)nd * ((double)nd1 + 1.0)
@@ -652,7 +652,7 @@ __device__ void qd_ground_pixel(const QdPixelRec* __restrict__ rec, QdWaveLds& W
     // left -- 9 cross-lane exchanges instead of 5 per dot.  Lane m ends up with dot (m >> 2) & 7.
     double v[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = (i < N) ? p * (double)n[i] : 0.0;
+    for (int i = 0; i < 8; ++i) v[i] = (i < N) ? p * (double)occ_of(i) : 0.0;
     {
         const bool b4 = (m & 16) != 0, b3 = (m & 8) != 0, b2 = (m & 4) != 0;
         double w4[4], w2[2];
