@@ -69,6 +69,19 @@ __device__ __forceinline__ double qd_rcp(double x) {
     r = fma(fma(-x, r, 1.0), r, r);
     return r;
 }
+// v_rcp_f64 / v_rsq_f64 deliver 4.6e-8 / 5.2e-8 relative accuracy on gfx950, one Newton step 2e-15 / 4e-15, two steps
+// 1.1e-16 / 2.4e-16 (scripts/proto/rcp_precision.hip).  One step is enough where the result only steers an iteration
+// (Laguerre's step) and for sqrt alone, whose own correction step squares the error away.
+__device__ __forceinline__ double qd_rcp1(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    return fma(fma(-x, r, 1.0), r, r);
+}
+__device__ __forceinline__ double qd_sqrt1(double x) {           // sqrt(x), x > 0, ~1 ulp
+    double y = __builtin_amdgcn_rsq(x);
+    y = y * fma(-0.5 * x * y, y, 1.5);
+    const double s = x * y;
+    return fma(fma(-s, s, x), 0.5 * y, s);
+}
 // sqrt(x) and 1/sqrt(x) from one v_rsq_f64 + two Newton steps (x > 0); ~1 ulp
 __device__ __forceinline__ void qd_sqrt_rsqrt(double x, double& s, double& r) {
     double y = __builtin_amdgcn_rsq(x);
@@ -244,8 +257,8 @@ __device__ void qd_ground_pixel(const QdPixelRec* __restrict__ rec, QdWaveLds& W
                 // Y < 0: s_j = s_i - e_d + e_{d+1} (forward); else backward
                 const double prod = (Y < 0) ? (double)nd * ((double)nd1 + 1.0)
                                             : (double)nd1 * ((double)nd + 1.0);
-                double sq_ = 0.0, rs_ = 0.0;
-                if (prod > 0.0) qd_sqrt_rsqrt(prod, sq_, rs_);
+                double sq_ = 0.0;
+                if (prod > 0.0) sq_ = qd_sqrt1(prod);
                 c = -t * sq_;
             }
 #pragma unroll
@@ -457,15 +470,15 @@ __device__ void qd_ground_pixel(const QdPixelRec* __restrict__ rec, QdWaveLds& W
             if (!conv) {
                 if (p1 == 0.0) conv = true;
                 else {
-                    const double ip = qd_rcp(p1);
+                    const double ip = qd_rcp1(p1);
                     const double G = d1 * ip, E = e1 * ip;
                     double disc = (dk - 1.0) * ((dk - 1.0) * G * G - dk * E);
                     // the iterate needs no correctly rounded sqrt / quotient (the fixed point does not depend
-                    // on them): rsq + Newton and rcp + Newton are a third of the IEEE sequences' instructions
-                    double sq = 0.0, rs_ = 0.0;
-                    if (disc > 0.0) qd_sqrt_rsqrt(disc, sq, rs_);
+                    // on them): rsq / rcp + one Newton step (2e-15) are a quarter of the IEEE sequences' instructions
+                    double sq = 0.0;
+                    if (disc > 0.0) sq = qd_sqrt1(disc);
                     const double den = (G < 0.0) ? G - sq : G + sq;
-                    const double xn = (den != 0.0) ? fma(-dk, qd_rcp(den), xl) : xl;
+                    const double xn = (den != 0.0) ? fma(-dk, qd_rcp1(den), xl) : xl;
                     if (!(xn > xl)) conv = true;                       // monotone sequence has stalled
                     else {
                         const double st = xn - xl, tol = 4e-16 * fmax(fabs(xn), fabs(xl));
