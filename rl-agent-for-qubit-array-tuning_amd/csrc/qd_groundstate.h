@@ -320,8 +320,14 @@ __device__ void qd_ground_pixel(const QdPixelRec* __restrict__ rec, QdWaveLds& W
     int k = solve ? 0 : 1;
     bool done = !solve;
     const int jmax = smax;                                 // (loop bound only: the loops stop when no lane is running)
+    // The LDS rows of neighbour slots nobody uses (slots >= maxcnt) keep the Lanczos vectors q_j when every component of
+    // the wave fits: pass 2 (x = sum_j y_j q_j) then reads them back instead of replaying the recurrence with its matvecs.
+    const int nfree = (QD_NBMAX - QD_NBREG) - (maxcnt > QD_NBREG ? maxcnt - QD_NBREG : 0);
+    const bool qstash = smax <= nfree;
+    double lo_run = INFINITY;                              // Gershgorin lower bound of T, kept while its rows appear
     for (int j = 0; j < jmax; ++j) {
         if (!__any(!done)) break;
+        if (qstash) W.coef[(QD_NBMAX - QD_NBREG - 1) - j][lane] = q;
         // matvec: q is published once and every neighbour's entry is one 64-bit LDS read (a 64-bit
         // cross-lane shuffle would be two ds_bpermute each); LDS operations of a wave complete in order,
         // so the reduction below may overwrite the buffer without another barrier
@@ -344,7 +350,9 @@ __device__ void qd_ground_pixel(const QdPixelRec* __restrict__ rec, QdWaveLds& W
             anorm = fmax(anorm, fmax(fabs(a), b));
             if (r == j) { al_mine = a; be_mine = b; ib_mine = ib; }
             k = j + 1;
-            if (j + 1 >= ssz || !(b > 1e-13 * anorm)) {
+            const bool last = j + 1 >= ssz || !(b > 1e-13 * anorm);
+            lo_run = fmin(lo_run, a - bp - (last ? 0.0 : b));         // row j: alpha_j - beta_{j-1} - beta_j
+            if (last) {
                 done = true;
                 if (r == j) be_mine = 0.0;
             } else {
@@ -366,16 +374,7 @@ __device__ void qd_ground_pixel(const QdPixelRec* __restrict__ rec, QdWaveLds& W
     // (3-4 iterations; validated against eigvalsh over 12 decades of scale).  p, p', p''
     // come from the three-term recurrence of the leading minors, rescaled together.
     // Every member lane runs the same computation on the rows published in al/be.
-    double lo, hi;
-    {
-        const unsigned below = seg & lt;
-        const int prev = below ? 31 - __builtin_clz(below) : m;
-        const double bprev = (r > 0 && r < k) ? be[hb + prev] : 0.0;
-        const double bme = (r < k - 1) ? be_mine : 0.0;
-        const double g = (r < k) ? al_mine - fabs(bprev) - fabs(bme) : INFINITY;
-        lo = qd_seg_min(g, MB, ssz, buf, hb);                       // Gershgorin lower bound
-        hi = lo;
-    }
+    double lo = solve ? lo_run : F, hi = lo;               // Gershgorin lower bound of T (T = [F] where nothing was solved)
     // scale of T: ||T|| <= max_j (|alpha_j| + 2 beta_j) <= 3 anorm (the maximum Lanczos kept; component-uniform) -- two more
     // segment reductions (min alpha, max beta) would buy nothing
     const double tscale = fmax(fabs(lo), 3.0 * anorm);
@@ -591,6 +590,17 @@ __device__ void qd_ground_pixel(const QdPixelRec* __restrict__ rec, QdWaveLds& W
         bool done2 = !solve;
 #endif
         unsigned mm = seg;
+        if (qstash) {
+            // the Lanczos vectors are still in LDS: no recurrence to replay
+            for (int j = 0; j < jmax; ++j) {
+                if (!__any(!done2)) break;
+                if (!done2) {
+                    const int bb = __builtin_ctz(mm); mm &= mm - 1;
+                    x = fma(W.yv[hb + bb] * yscale, W.coef[(QD_NBMAX - QD_NBREG - 1) - j][lane], x);
+                    if (j + 1 >= k) done2 = true;
+                }
+            }
+        }
         for (int j = 0; j < jmax; ++j) {
             if (!__any(!done2)) break;
             double yj = 0.0, a = 0.0, b = 0.0, ib = 0.0;
