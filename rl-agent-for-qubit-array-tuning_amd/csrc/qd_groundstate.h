@@ -360,9 +360,25 @@ __device__ void qd_ground_pixel(const QdPixelRec* __restrict__ rec, QdWaveLds& W
             }
         }
     }
-    W.al[lane] = al_mine;
-    W.be[lane] = (r < k - 1) ? be_mine : 0.0;
+    // T is published SCALED by a power of two (exact) so that ||T|| lies in [1, 2): the minors of the Laguerre recurrences
+    // then grow by at most 5 per row and need no rescaling at all -- with tc up to 1e44 in the random-action regime the
+    // unscaled minors of a 12-row T overflowed between two rescalings (a wrong eigenvalue in a handful of pixels of the
+    // 458 752-pixel sweep of round 2).  Scale of T: ||T|| <= max_j (|alpha_j| + 2 beta_j) <= 3 anorm (the maximum Lanczos
+    // kept; component-uniform) or the Gershgorin bound kept while its rows appeared.
+    const double lo_uns = solve ? lo_run : F;
+    const double tscale_uns = fmax(fabs(lo_uns), 3.0 * anorm);
+    double tsc = 1.0, tusc = 1.0;                          // 2^-E and 2^E, E = exponent of the scale
+    {
+        const unsigned long long ef = ((unsigned long long)__double_as_longlong(tscale_uns) >> 52) & 0x7FFull;
+        if (ef != 0ull && ef < 2046ull) {
+            tsc = __longlong_as_double((long long)((2046ull - ef) << 52));
+            tusc = __longlong_as_double((long long)(ef << 52));
+        }
+    }
+    W.al[lane] = al_mine * tsc;
+    W.be[lane] = (r < k - 1) ? be_mine * tsc : 0.0;
     W.ib[lane] = ib_mine;
+    al_mine *= tsc; be_mine *= tsc;
     __builtin_amdgcn_wave_barrier();
     qd_lds_cvptr al = (qd_lds_cvptr)W.al;
     qd_lds_cvptr be = (qd_lds_cvptr)W.be;
@@ -374,10 +390,8 @@ __device__ void qd_ground_pixel(const QdPixelRec* __restrict__ rec, QdWaveLds& W
     // (3-4 iterations; validated against eigvalsh over 12 decades of scale).  p, p', p''
     // come from the three-term recurrence of the leading minors, rescaled together.
     // Every member lane runs the same computation on the rows published in al/be.
-    double lo = solve ? lo_run : F, hi = lo;               // Gershgorin lower bound of T (T = [F] where nothing was solved)
-    // scale of T: ||T|| <= max_j (|alpha_j| + 2 beta_j) <= 3 anorm (the maximum Lanczos kept; component-uniform) -- two more
-    // segment reductions (min alpha, max beta) would buy nothing
-    const double tscale = fmax(fabs(lo), 3.0 * anorm);
+    double lo = lo_uns * tsc, hi = lo;                     // Gershgorin lower bound of the scaled T (T = [F] where nothing was solved)
+    const double tscale = tscale_uns * tsc;                // in [1, 2)
     double xl = lo - (1e-3 * tscale + 1e-300);
 #if defined(QD_DEBUG_STATS)
     int dbg_myits = 0, dbg_waveits = 0;                    // diagnostic build (scripts/solver_stats.py)
@@ -389,19 +403,14 @@ __device__ void qd_ground_pixel(const QdPixelRec* __restrict__ rec, QdWaveLds& W
         bool conv = k <= 1;
 #endif
         const double dk = (double)k;
-        const bool huge_scale = __any(tscale > 1e30);
-        // |alpha_j|, beta_j <= anorm (Lanczos kept the maximum), |xl| <= 3.01 anorm: a minor grows by less than a factor
-        // 5 anorm per row and shrinks by no more than ~anorm, so eight rows from p_0 = 1 stay inside the double range
-        // without any rescaling when 1e-10 < anorm < 1e30 (wave-uniform test; the tail loop rescales on its own)
-        const bool rescale8 = __any(solve && !(anorm < 1e30 && anorm > 1e-10));
         double sprev = 0.0;                                // previous Laguerre step (0: none yet)
         for (int it = 0; it < 48; ++it) {
             if (!__any(!conv)) break;
 #if defined(QD_DEBUG_STATS)
             dbg_waveits = it + 1; if (!conv) dbg_myits = it + 1;
 #endif
-            // p, p', p'' at xl: three-term recurrences over the rows of T.  The first 8 rows use the
-            // register-resident member slots (no bit scanning); magnitudes are rescaled every 4 rows.
+            // p, p', p'' at xl: three-term recurrences over the rows of the scaled T (|entries| <= 2: no rescaling needed).
+            // The first 8 rows use the register-resident member slots (no bit scanning).
             double p0 = 1.0, p1 = 1.0, d0 = 0.0, d1 = 0.0, e0 = 0.0, e1 = 0.0, bprev = 0.0;
 #define QD_LAG_ROW(AL, BE, FIRST)                                                   \
             {                                                                       \
@@ -416,13 +425,6 @@ __device__ void qd_ground_pixel(const QdPixelRec* __restrict__ rec, QdWaveLds& W
                 }                                                                   \
                 p0 = p1; p1 = p2_; d0 = d1; d1 = d2_; e0 = e1; e1 = e2_;            \
                 bprev = (BE);                                                       \
-            }
-#define QD_LAG_RESCALE()                                                            \
-            {                                                                       \
-                const double ap_ = fabs(p1);                                        \
-                double sc_ = 1.0;                                                   \
-                if (ap_ > 1e100) sc_ = 1e-100; else if (ap_ < 1e-100 && ap_ > 0.0) sc_ = 1e100; \
-                if (sc_ != 1.0) { p0 *= sc_; p1 *= sc_; d0 *= sc_; d1 *= sc_; e0 *= sc_; e1 *= sc_; } \
             }
             // Unrolled rows 0..7 ping-pong between the two register sets (even rows overwrite the "older"
             // set 0, odd rows set 1) instead of rotating p0 <- p1 <- p2: inside predicated blocks the
@@ -448,9 +450,6 @@ __device__ void qd_ground_pixel(const QdPixelRec* __restrict__ rec, QdWaveLds& W
                     if (i & 1) { QD_LAG_ROW_PP(al[MB.idx[i]], be[MB.idx[i]], false, p1, p0, d1, d0, e1, e0) }
                     else       { QD_LAG_ROW_PP(al[MB.idx[i]], be[MB.idx[i]], i == 0, p0, p1, d0, d1, e0, e1) }
                 }
-                // eight rows grow the minors by at most (2 tscale)^8 from 1: one rescale at the end is enough
-                // unless the matrix scale itself is astronomic (wave-uniform test)
-                if ((i == 7 && (rescale8 || kmax > 8)) || (i == 3 && huge_scale)) QD_LAG_RESCALE()
             }
 #undef QD_LAG_ROW_PP
             {
@@ -460,12 +459,10 @@ __device__ void qd_ground_pixel(const QdPixelRec* __restrict__ rec, QdWaveLds& W
                         const int b = __builtin_ctz(mm); mm &= mm - 1;
                         QD_LAG_ROW(al[hb + b], be[hb + b], false)
                     }
-                    if ((i & 3) == 3) QD_LAG_RESCALE()
                 }
             }
             if (k < 8 && (k & 1)) { p1 = p0; d1 = d0; e1 = e0; }      // odd row count: the current values sit in set 0
 #undef QD_LAG_ROW
-#undef QD_LAG_RESCALE
             if (!conv) {
                 if (p1 == 0.0) conv = true;
                 else {
@@ -496,7 +493,7 @@ __device__ void qd_ground_pixel(const QdPixelRec* __restrict__ rec, QdWaveLds& W
         }
     }
     // component-uniform eigenvalue: T = [alpha_0] when k <= 1 (row 0 = first member)
-    const double lam = (k <= 1) ? al[hb + __builtin_ctz(seg)] : xl;
+    const double lam = (k <= 1) ? al[hb + __builtin_ctz(seg)] : xl;      // in the scaled units of T
     lo = (k <= 1) ? lam : xl - 2e-16 * tscale;                          // shift for the inverse iteration
     hi = lam;
 
@@ -508,12 +505,18 @@ __device__ void qd_ground_pixel(const QdPixelRec* __restrict__ rec, QdWaveLds& W
     {
         const double sig = lo;
         const double tiny = 1e-300 + 1e-18 * fmax(fabs(lo), fabs(hi));
-        // the factorisation sweep also does the forward substitution of the first iteration (right-hand side of ones)
+        // The factorisation sweep also does the forward substitution of the first iteration.  Right-hand side e_1 (the first
+        // Lanczos vector), not ones: plain Lanczos leaves GHOST copies of a converged Ritz value in T (orthogonality of Q is
+        // lost completely once tc >~ 1e10), the copies lie closer together than any shift can tell apart, and the inverse
+        // iteration returns a mixture sum_i w_i s_i of their eigenvectors s_i.  Every copy's Ritz vector is Q s_i =
+        // (s_i1 / gamma) v (v the true vector, gamma = q_1 . v), so the mixture is coherent exactly when the weights carry
+        // the sign of s_i1: from e_1 they are w_i = s_i1 / (theta_i - sigma)^2.  From ones the signs are arbitrary, copies
+        // cancelled, and the occupations of a few random-action pixels were off by 1e-5 .. 4e-3 (eigen residual 1e-5).
         double d = 1.0, bprev = 0.0, rdp = 1.0, zfac = 0.0;
 #define QD_FAC_ROW(SLOT, FIRST)                                                     \
         {                                                                           \
             double di_ = al[SLOT] - sig, z_ = 1.0;                                  \
-            if (!(FIRST)) { const double l_ = bprev * rdp; di_ = di_ - l_ * bprev; W.lf[SLOT] = l_; z_ = 1.0 - l_ * zfac; } \
+            if (!(FIRST)) { const double l_ = bprev * rdp; di_ = di_ - l_ * bprev; W.lf[SLOT] = l_; z_ = -(l_ * zfac); } \
             if (!(di_ > tiny)) di_ = tiny;                                          \
             d = di_;                                                                \
             rdp = qd_rcp(d);                                /* 1/d_i: stored, and reused as 1/d_{i-1} by the next row */ \
@@ -604,7 +607,7 @@ __device__ void qd_ground_pixel(const QdPixelRec* __restrict__ rec, QdWaveLds& W
         for (int j = 0; j < jmax; ++j) {
             if (!__any(!done2)) break;
             double yj = 0.0, a = 0.0, b = 0.0, ib = 0.0;
-            if (!done2) { const int bb = __builtin_ctz(mm); mm &= mm - 1; yj = W.yv[hb + bb] * yscale; a = al[hb + bb]; b = be[hb + bb]; ib = W.ib[hb + bb]; }
+            if (!done2) { const int bb = __builtin_ctz(mm); mm &= mm - 1; yj = W.yv[hb + bb] * yscale; a = al[hb + bb] * tusc; b = be[hb + bb] * tusc; ib = W.ib[hb + bb]; }
             double w = F * q2;
             buf[lane] = q2;
             __builtin_amdgcn_wave_barrier();
@@ -632,7 +635,7 @@ __device__ void qd_ground_pixel(const QdPixelRec* __restrict__ rec, QdWaveLds& W
     }
 
     // ---- 8. pick the lowest component, expectation occupations --------------
-    const double mylam = active ? lam : INFINITY;
+    const double mylam = active ? lam * tusc : INFINITY;   // back to energy units (exact)
     const double best = qd_half_min(mylam);
     // tie between components (exactly equal energies): the state with the lowest candidate
     // index wins -- the reference order puts it first -- independent of the buffer order

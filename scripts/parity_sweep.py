@@ -14,6 +14,7 @@ from qadapt_hip.vec_env import VecQuantumDeviceEnv, SyntheticCapacitanceModel
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 12
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+only = [int(x) for x in sys.argv[4].split(",")] if len(sys.argv) > 4 else None      # optional: compare these envs only
 R = 64
 env = VecQuantumDeviceEnv(B, num_dots=N, resolution=R, seed=1234, validate=True, capacitance_model=SyntheticCapacitanceModel(99))
 env.reset()
@@ -27,7 +28,7 @@ cand = env.candidates(); occ = env.occupations(); raw, _ = env.raw(); eig = env.
 tot = dict(px=0, mism=0, unres=0, wocc=0.0, wsig=0.0, wres=0.0, wresok=0.0, wlam=0.0)
 dec = {}     # unresolvable pixels by decade of rel_gap: [count, count with |occ - oracle| > 1e-3, > 1e-6]
 t0 = time.time()
-for e in range(B):
+for e in (range(B) if only is None else only):
     dev = H.dev_view(N, env._params_host[e]); sv = H.state_view(N, st[e])
     m = u = 0; wo = ws = wr = wrk = wl = 0.0; tcm = 0.0
     for ch in range(N - 1):
