@@ -279,7 +279,7 @@ __device__ __forceinline__ void qd_tile_solve(const QdTileGroundLds& Gd, QdTileG
                     }
                     p0 = p1; p1 = p2_; d0 = d1; d1 = d2_; e0 = e1; e1 = e2_;
                     bprev = be[i];
-                    if ((i & 3) == 3) {
+                    if (i & 1) {                         // every second row: two rows of a T with entries ~1e44 stay inside the double range, four do not
                         const double ap_ = fabs(p1);
                         double sc_ = 1.0;
                         if (ap_ > 1e100) sc_ = 1e-100; else if (ap_ < 1e-100 && ap_ > 0.0) sc_ = 1e100;
@@ -338,7 +338,7 @@ __device__ __forceinline__ void qd_tile_solve(const QdTileGroundLds& Gd, QdTileG
 #pragma unroll
             for (int i = 0; i < M; ++i) {
                 if (i < k) {
-                    const double rhs_ = (iter == 0) ? 1.0 : y[i];
+                    const double rhs_ = (iter == 0) ? (i == 0 ? 1.0 : 0.0) : y[i];      // from e_1, not ones: ghost copies then add up coherently (qd_groundstate.h, 6b)
                     const double z_ = (i == 0) ? rhs_ : rhs_ - lf[i] * zprev;
                     y[i] = z_ * rd[i];
                     zprev = z_;

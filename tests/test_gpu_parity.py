@@ -651,3 +651,40 @@ def test_config2_shape_in_product_mode_against_oracle():
             assert np.abs(full - img[e]).max() <= 2e-6, (e, np.abs(full - img[e]).max())
     print(f"[parity, product mode] config-2 shape: max relative signal error over resolvable pixels {worst:.2e}")
     env.close()
+
+
+def test_random_action_regime_findings_of_the_round2_sweep_stay_fixed():
+    """Two defects that only the 458 752-pixel sweep of the bench's regime showed (scripts/parity_sweep.py 8 16 4), kept as a
+    test on exactly those envs: 16 8-dot 64x64 envs, seed 1234, four random-action steps.
+      env 8  (tc up to 4e44, a 12-state winning component): the minors of T overflowed between two rescalings -> an
+             eigenvalue off by 0.2 ||H|| and occupations off by 1 in one pixel family (fixed: T is scaled to ||T|| in [1,2));
+      env 13 (tc ~ 1e21): ghost copies of the converged Ritz value cancelled in the inverse iteration -> occupations off
+             by 1e-5 at an eigen residual of 1e-5 (fixed: inverse iteration starts from e_1)."""
+    import torch
+    from qadapt_hip.vec_env import VecQuantumDeviceEnv, SyntheticCapacitanceModel
+    N, B, R = 8, 16, 64
+    env = VecQuantumDeviceEnv(B, num_dots=N, resolution=R, seed=1234, validate=True, capacitance_model=SyntheticCapacitanceModel(99))
+    env.reset()
+    gen = torch.Generator(device="cpu").manual_seed(99)
+    for _ in range(4):
+        env.step((torch.rand((B, 2 * N - 1), generator=gen) * 2 - 1).cuda())
+    st, _ = env.get_state()
+    env.observe()
+    cand = env.candidates(); occ = env.occupations(); eig = env.eigen()
+    for e, occ_tol in ((8, 1e-6), (13, 5e-6)):
+        dev = H.dev_view(N, env._params_host[e]); sv = H.state_view(N, st[e])
+        worst_occ = worst_lam = 0.0; tcmax = 0.0
+        for ch in range(N - 1):
+            ref = OC.csd_channel(dev, sv.vgm, dev.origin, sv.gate_v, sv.sensor_gt, sv.barrier_v, dev.window, ch, R)
+            assert np.array_equal(cand[e, ch], ref["states"]), (e, ch)
+            sp = H.pixel_spectrum(dev, sv.vgm, dev.origin, sv.gate_v, sv.sensor_gt, sv.barrier_v, dev.window, ch, R, states=ref["states"])
+            worst_lam = max(worst_lam, float((np.abs(eig[e, ch, :, 0] - sp["lam0"]) / sp["hnorm"]).max()))
+            ok = sp["rel_gap"] > H.GAP_MIN
+            if ok.any():
+                worst_occ = max(worst_occ, float(np.abs(occ[e, ch] - ref["occ"]).max(axis=1)[ok].max()))
+            tcmax = max(tcmax, float(sp["tcmax"].max()))
+        print(f"[round-2 sweep findings] env {e}: max tc {tcmax:.1e}, max |lam - lam_oracle| / ||H|| {worst_lam:.1e}, "
+              f"max |occ - oracle| over resolvable pixels {worst_occ:.1e}")
+        assert worst_lam <= 1e-10, (e, worst_lam)
+        assert worst_occ <= occ_tol, (e, worst_occ)
+    env.close()
