@@ -7,9 +7,10 @@ import numpy as np, torch
 from qadapt_hip.vec_env import VecQuantumDeviceEnv, SyntheticCapacitanceModel
 N, R = 8, 64
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 12; steps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
-env = VecQuantumDeviceEnv(B, num_dots=N, resolution=R, seed=1234, validate=True, capacitance_model=SyntheticCapacitanceModel(99))
+seed = int(os.environ.get("QD_SWEEP_SEED", "1234"))
+env = VecQuantumDeviceEnv(B, num_dots=N, resolution=R, seed=seed, validate=True, capacitance_model=SyntheticCapacitanceModel(99))
 env.reset()
-gen = torch.Generator(device="cpu").manual_seed(99)
+gen = torch.Generator(device="cpu").manual_seed(99 + seed - 1234)
 for t in range(steps):
     env.step((torch.rand((B, 2 * N - 1), generator=gen) * 2 - 1).cuda())
 st, _ = env.get_state(); env.observe()

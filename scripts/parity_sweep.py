@@ -16,9 +16,10 @@ B = int(sys.argv[2]) if len(sys.argv) > 2 else 12
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 only = [int(x) for x in sys.argv[4].split(",")] if len(sys.argv) > 4 else None      # optional: compare these envs only
 R = 64
-env = VecQuantumDeviceEnv(B, num_dots=N, resolution=R, seed=1234, validate=True, capacitance_model=SyntheticCapacitanceModel(99))
+seed = int(os.environ.get("QD_SWEEP_SEED", "1234"))      # other seeds: other devices and action sequences
+env = VecQuantumDeviceEnv(B, num_dots=N, resolution=R, seed=seed, validate=True, capacitance_model=SyntheticCapacitanceModel(99))
 env.reset()
-gen = torch.Generator(device="cpu").manual_seed(99)
+gen = torch.Generator(device="cpu").manual_seed(99 + seed - 1234)
 for t in range(steps):
     env.step((torch.rand((B, 2 * N - 1), generator=gen) * 2 - 1).cuda())
 st, _ = env.get_state()
@@ -49,7 +50,7 @@ for e in (range(B) if only is None else only):
           f"max eigen residual {wr:.1e} (resolvable pixels {wrk:.1e}), max |lam-lam_oracle|/|H| {wl:.1e}, max tc {tcm:.1e}", flush=True)
     tot["px"] += (N - 1) * R * R; tot["mism"] += m; tot["unres"] += u
     tot["wocc"] = max(tot["wocc"], wo); tot["wsig"] = max(tot["wsig"], ws); tot["wres"] = max(tot["wres"], wr); tot["wresok"] = max(tot["wresok"], wrk); tot["wlam"] = max(tot["wlam"], wl)
-print(f"TOTAL {N}-dot {R}x{R}, {B} envs after {steps} random-action steps: {tot['px']} pixels, {tot['mism']} state-list mismatches, "
+print(f"TOTAL {N}-dot {R}x{R}, {B} envs (seed {seed}) after {steps} random-action steps: {tot['px']} pixels, {tot['mism']} state-list mismatches, "
       f"{tot['unres']} unresolvable in float64 (rel_gap <= {H.GAP_MIN}), max |occ-oracle| {tot['wocc']:.2e}, max rel signal err {tot['wsig']:.2e}, "
       f"max eigen residual {tot['wres']:.2e} (resolvable pixels {tot['wresok']:.2e}), max |lam-lam_oracle|/|H| {tot['wlam']:.2e}; search stats {env.search_stats()}; oracle time {time.time()-t0:.0f}s")
 print("unresolvable pixels by decade of rel_gap (10^d): count, |occ-oracle| > 1e-3, > 1e-6")
