@@ -36,10 +36,8 @@ extern "C" {
 #define QD_FLAG_VALIDATE 1    /* keep per-pixel candidate records and occupations  */
 #define QD_FLAG_PIXEL_SEARCH 2 /* a9 by the per-pixel search only (default: one search per 8x8 pixel tile where the
                                  grid is fine enough, with an exact per-pixel redo pass; same results, A/B switch) */
-#define QD_FLAG_TILE_FUSED 4  /* experimental: one fused kernel per 8x8 tile does the search AND the ground state with one pixel
-                                 per lane (csrc/qd_tile_ground.h).  Same results to round-off (its eigenpairs have the smaller
-                                 residuals) and no 488-B/pixel record hand-off, but slower than the default pipeline on
-                                 gfx950 today */
+#define QD_FLAG_RETIRED_TILE_FUSED 4  /* was QD_FLAG_TILE_FUSED (round 2: experimental fused tile kernel, 3x slower than the
+                                 default pipeline); the kernel is gone and qd_create refuses the flag with QD_ERR_ARG */
 
 /* Stochastic stages.  The generators are counter-based Philox streams, so
  * results are reproducible per (rng_seed, global env id, observation number, channel, pixel)
@@ -171,6 +169,10 @@ int qd_get_eigen(qd_handle* h, double* eig_host);
  * whole to the per-pixel search, single pixels redone, sum of superset sizes, pixels redone for < 32 valid states;
  * [8 + r]: tiles handed over by reason r (1 ranges, 2 seeds, 3 frontier overflow, 4 too few leaves, 5 superset size). */
 int qd_get_search_stats(qd_handle* h, uint64_t* out16);
+/* Counters of the ground-state kernel's eigen-solver phase since qd_create (QD_FLAG_VALIDATE): tasks (hop components of
+ * >= 2 states solved), sum of their Laguerre iterations, 64-task wave tiles, sum over tiles of the largest iteration count
+ * in the tile; [4 + k]: tasks of size class k (2, 3, .. 8 states, then 9..32). */
+int qd_get_solver_stats(qd_handle* h, uint64_t* out16);
 /* Checkpointing of the stochastic stages (SURVEY 5 "expose RNG seeds/counters"): the Philox
  * counter word that numbers the observations rendered so far by this handle. */
 int qd_get_rng_state(const qd_handle* h, uint64_t* obs_serial);

@@ -21,9 +21,10 @@ struct qd_handle {
     size_t recs_envs;                       // envs the recs buffer holds
     float *gimg, *pimg, *bimg, *volt;
     unsigned long long* tel; int tel_words;
-    unsigned long long* tstats;             // tile-search counters (validate mode)
-    int tile_search;                        // 0: per-pixel kernels only; 1: tile-shared candidate search + qd_k_ground; 2: fused tile kernel
-    unsigned char* redo;                    // [chunk][C][P] pixels the fused tile kernel hands to the per-pixel kernels
+    unsigned long long* tstats;             // tile-search [0..15] and eigen-solver [16..31] counters (validate mode)
+    int tile_search;                        // 0: per-pixel search only; 1: tile-shared candidate search + exact redo pass
+    unsigned char* slabs;                   // private scratch of the persistent ground-state blocks (qd_gs_slab_bytes each)
+    int gs_blocks;                          // blocks the ground-state kernel is launched with (= slabs)
     unsigned long long obs_serial;
     char err[512];
 };
@@ -106,6 +107,7 @@ extern "C" int qd_create(const qd_config* cfg, int device, qd_handle** out) {
     if (cfg->n_dot < 2 || cfg->n_dot > QD_MAXN || cfg->resolution < 2 || cfg->batch < 1) return QD_ERR_ARG;
     if (cfg->cnn_outputs != 2 && cfg->cnn_outputs != 3) return QD_ERR_ARG;
     if (cfg->gate_curve_type < 0 || cfg->gate_curve_type > 3 || cfg->update_method < 0 || cfg->update_method > 1) return QD_ERR_ARG;
+    if (cfg->flags & QD_FLAG_RETIRED_TILE_FUSED) return QD_ERR_ARG;      // the fused tile kernel of round 2 is gone
     qd_handle* h = new (std::nothrow) qd_handle();
     if (!h) return QD_ERR_NOMEM;
     memset(h, 0, sizeof(*h));
@@ -143,14 +145,25 @@ extern "C" int qd_create(const qd_config* cfg, int device, qd_handle** out) {
         QD_HIP(hipMalloc(&h->occ, sizeof(double) * (size_t)h->B * h->C * h->P * h->N));
     // the tile-shared search pays off where neighbouring pixels are close in voltage (fine grids) and needs >= 32
     // candidates valid across a tile (N >= 4); otherwise every pixel is searched on its own
-    h->tile_search = (h->N >= 4 && h->R >= 32 && !(cfg->flags & QD_FLAG_PIXEL_SEARCH)) ? ((cfg->flags & QD_FLAG_TILE_FUSED) ? 2 : 1) : 0;
-    if (h->tile_search == 2) {
-        QD_HIP(hipMalloc(&h->redo, (size_t)h->recs_envs * h->C * h->P));
-        QD_HIP(hipMemset(h->redo, 0, (size_t)h->recs_envs * h->C * h->P));
+    h->tile_search = (h->N >= 4 && h->R >= 32 && !(cfg->flags & QD_FLAG_PIXEL_SEARCH)) ? 1 : 0;
+    {
+        // persistent ground-state blocks: as many as are resident at once (never more than there are batches), one slab each
+        const bool val = (cfg->flags & QD_FLAG_VALIDATE) != 0;
+        hipDeviceProp_t prop;
+        QD_HIP(hipGetDeviceProperties(&prop, device));
+        int per_cu = 0;
+        if (val) { QD_DISPATCH_N(h->N, QD_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, qd_k_ground<NN, true>, QD_GS_BLOCK, 0))); }
+        else     { QD_DISPATCH_N(h->N, QD_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, qd_k_ground<NN, false>, QD_GS_BLOCK, 0))); }
+        if (per_cu < 1) per_cu = 1;
+        const long batches = (long)chunk * h->C * ((h->P + QD_GS_PPB - 1) / QD_GS_PPB);
+        long blocks = (long)prop.multiProcessorCount * per_cu;
+        if (blocks > batches) blocks = batches;
+        h->gs_blocks = (int)blocks;
+        QD_HIP(hipMalloc(&h->slabs, (size_t)blocks * qd_gs_slab_bytes(val)));
     }
     if (cfg->flags & QD_FLAG_VALIDATE) {
-        QD_HIP(hipMalloc(&h->tstats, sizeof(unsigned long long) * 16));
-        QD_HIP(hipMemset(h->tstats, 0, sizeof(unsigned long long) * 16));
+        QD_HIP(hipMalloc(&h->tstats, sizeof(unsigned long long) * 32));
+        QD_HIP(hipMemset(h->tstats, 0, sizeof(unsigned long long) * 32));
         QD_HIP(hipMalloc(&h->eig, sizeof(double) * 2 * (size_t)h->B * h->C * h->P));
         QD_HIP(hipMemset(h->eig, 0, sizeof(double) * 2 * (size_t)h->B * h->C * h->P));
     }
@@ -179,7 +192,7 @@ extern "C" int qd_create(const qd_config* cfg, int device, qd_handle** out) {
 extern "C" int qd_destroy(qd_handle* h) {
     if (!h) return QD_ERR_ARG;
     QdDeviceGuard guard_(h->device);
-    void* bufs[] = {h->params, h->state, h->steps, h->zraw, h->plohi, h->recs, h->occ, h->tel, h->eig, h->tstats, h->redo};
+    void* bufs[] = {h->params, h->state, h->steps, h->zraw, h->plohi, h->recs, h->occ, h->tel, h->eig, h->tstats, h->slabs};
     for (void* b : bufs) if (b) (void)hipFree(b);
     delete h;
     return QD_OK;
@@ -276,14 +289,15 @@ static QdNoiseCfg qd_noise_cfg(const qd_handle* h) {
     return nz;
 }
 
-static int qd_launch_ground(qd_handle* h, const int32_t* env_ids, int base, int cnt, hipStream_t s, const unsigned char* redo) {
-    dim3 g2((h->P + QD_GS_PPB - 1) / QD_GS_PPB, h->C, cnt);
+static int qd_launch_ground(qd_handle* h, const int32_t* env_ids, int base, int cnt, hipStream_t s) {
+    const long batches = (long)cnt * h->C * ((h->P + QD_GS_PPB - 1) / QD_GS_PPB);
+    const int blocks = (int)(batches < h->gs_blocks ? batches : h->gs_blocks);
     if (h->eig) {
-        QD_DISPATCH_N(h->N, qd_k_ground<NN, true><<<g2, dim3(QD_GS_BLOCK), 0, s>>>(env_ids, base, h->R,
-                                                h->params, h->recs, h->zraw, h->occ, h->state, h->cfg.noise_flags, h->eig, redo));
+        QD_DISPATCH_N(h->N, qd_k_ground<NN, true><<<dim3(blocks), dim3(QD_GS_BLOCK), 0, s>>>(env_ids, base, cnt, h->R,
+                                                h->params, h->recs, h->zraw, h->occ, h->state, h->cfg.noise_flags, h->eig, h->slabs, h->tstats));
     } else {
-        QD_DISPATCH_N(h->N, qd_k_ground<NN, false><<<g2, dim3(QD_GS_BLOCK), 0, s>>>(env_ids, base, h->R,
-                                                h->params, h->recs, h->zraw, h->occ, h->state, h->cfg.noise_flags, nullptr, redo));
+        QD_DISPATCH_N(h->N, qd_k_ground<NN, false><<<dim3(blocks), dim3(QD_GS_BLOCK), 0, s>>>(env_ids, base, cnt, h->R,
+                                                h->params, h->recs, h->zraw, h->occ, h->state, h->cfg.noise_flags, nullptr, h->slabs, nullptr));
     }
     QD_HIP(hipGetLastError());
     return QD_OK;
@@ -300,43 +314,24 @@ static int qd_launch_ground(qd_handle* h, const int32_t* env_ids, int base, int 
     }
 
 // a5-a13 for `cnt` envs starting at list position `base`.
-//   tile_search 2: fused tile kernel (search + ground state, one wave per 8x8 tile), then the per-pixel kernels on the
-//                  pixels it handed over;  1: tile search + exact redo pass, then qd_k_ground;  0: per-pixel kernels.
-static int qd_launch_csd(qd_handle* h, const int32_t* env_ids, int base, int cnt, hipStream_t s, int what /*1 cand, 2 ground, 3 both*/) {
+//   tile_search 1: tile search + exact redo pass, then qd_k_ground;  0: per-pixel search, then qd_k_ground.
+static int qd_launch_csd(qd_handle* h, const int32_t* env_ids, int base, int cnt, hipStream_t s, int what /*1 search, 2 ground, 3 both*/) {
     const size_t shm = (size_t)QD_K * QD_CAND_BLOCK * (sizeof(double) + sizeof(uint16_t));
     const int sorted = (h->cfg.flags & QD_FLAG_VALIDATE) ? 1 : 0;
     dim3 g1(qd_cand_blocks(h->R), h->C, cnt);
     const int tiles = ((h->R + 7) / 8) * ((h->R + 7) / 8);
     dim3 gt(tiles, h->C, cnt);
-    if (h->tile_search == 2) {
-        if (what & 1) {
-            if (sorted) {
-                QD_DISPATCH_TILE(h->N, qd_k_tile<NN, 1, true><<<gt, dim3(64), 0, s>>>(env_ids, base, h->R, h->params, h->state, h->recs,
-                                 1, h->cfg.noise_flags, h->tstats, h->zraw, h->occ, h->eig, h->redo));
-            } else {
-                QD_DISPATCH_TILE(h->N, qd_k_tile<NN, 1, false><<<gt, dim3(64), 0, s>>>(env_ids, base, h->R, h->params, h->state, nullptr,
-                                 0, h->cfg.noise_flags, nullptr, h->zraw, h->occ, nullptr, h->redo));
-            }
-            QD_HIP(hipGetLastError());
-            QD_DISPATCH_N(h->N, qd_k_candidates<NN><<<g1, dim3(QD_CAND_BLOCK), shm, s>>>(env_ids, base, h->R, h->params, h->state, h->recs,
-                                                                                          sorted, h->cfg.noise_flags, 2, h->redo));
-            QD_HIP(hipGetLastError());
-            int rc = qd_launch_ground(h, env_ids, base, cnt, s, h->redo);
-            if (rc) return rc;
-        }
-        return QD_OK;
-    }
     if (what & 1) {
         if (h->tile_search == 1) {
-            QD_DISPATCH_TILE(h->N, qd_k_tile<NN, 0, false><<<gt, dim3(64), 0, s>>>(env_ids, base, h->R, h->params, h->state, h->recs,
-                             sorted, h->cfg.noise_flags, h->tstats, nullptr, nullptr, nullptr, nullptr));
+            QD_DISPATCH_TILE(h->N, qd_k_tile<NN><<<gt, dim3(64), 0, s>>>(env_ids, base, h->R, h->params, h->state, h->recs,
+                             sorted, h->cfg.noise_flags, h->tstats));
             QD_HIP(hipGetLastError());
         }
         QD_DISPATCH_N(h->N, qd_k_candidates<NN><<<g1, dim3(QD_CAND_BLOCK), shm, s>>>(env_ids, base, h->R, h->params, h->state, h->recs,
-                                                                                      sorted, h->cfg.noise_flags, h->tile_search, nullptr));
+                                                                                      sorted, h->cfg.noise_flags, h->tile_search));
         QD_HIP(hipGetLastError());
     }
-    if (what & 2) return qd_launch_ground(h, env_ids, base, cnt, s, nullptr);
+    if (what & 2) return qd_launch_ground(h, env_ids, base, cnt, s);
     return QD_OK;
 }
 
@@ -479,6 +474,15 @@ extern "C" int qd_get_search_stats(qd_handle* h, uint64_t* out16) {
     QD_ON_DEVICE(h);
     QD_HIP(hipDeviceSynchronize());
     QD_HIP(hipMemcpy(out16, h->tstats, sizeof(unsigned long long) * 16, hipMemcpyDeviceToHost));
+    return QD_OK;
+}
+
+extern "C" int qd_get_solver_stats(qd_handle* h, uint64_t* out16) {
+    if (!h || !out16) return QD_ERR_ARG;
+    if (!h->tstats) return qd_fail(h, QD_ERR_STATE, "qd_get_solver_stats needs QD_FLAG_VALIDATE");
+    QD_ON_DEVICE(h);
+    QD_HIP(hipDeviceSynchronize());
+    QD_HIP(hipMemcpy(out16, h->tstats + 16, sizeof(unsigned long long) * 16, hipMemcpyDeviceToHost));
     return QD_OK;
 }
 

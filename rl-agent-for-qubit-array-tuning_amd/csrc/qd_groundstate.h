@@ -1,45 +1,38 @@
-// qd_groundstate.h -- wave-level ground state of H = diag(F) + H_t over the 32
-// kept charge states of one pixel (reference:
-// hamiltonian_build.py:12-45, 75-137, 460-483 and ground_state.py:149-162).
+// qd_groundstate.h -- ground state of H = diag(F) + H_t over the 32 kept charge states of a pixel (SURVEY rows
+// a11-a13; reference: hamiltonian_build.py:12-45, 75-137, 460-483 and ground_state.py:149-162, where a dense 32x32
+// eigh is called per pixel and only column 0 is used).
 //
-// Mapping: ONE PIXEL PER HALF-WAVE (32 lanes), ONE BASIS STATE PER LANE; a
-// 64-lane wavefront works on two pixels at once.  All cross-lane traffic stays
-// inside a half (ds_bpermute via __shfl(..., 32)) or goes through a small
-// per-wave LDS area.
+// Three phases per batch of QD_GS_PPB pixels, all inside one persistent thread block (qd_k_ground, qd_kernels.h):
 //
-// Algorithm (numerics validated against numpy.linalg.eigh in
-// tests/proto_groundstate.py, which this file follows step by step):
-//   1. occupations of lane m's state; its free energy F_m comes with the record (the candidates
-//      kernel evaluated the canonical energy of every kept state).
-//   2. hop neighbours: states i,j are coupled over the adjacent pair d iff
-//      s_j - s_i = -+e_d +-e_{d+1}.  With 4-bit-spaced delta codes that is a borrow-free nibble
-//      difference of 0x1F << 4q or 0xF1 << 4q.  H_ij = -t_d sqrt(n_from (n_to + 1)) with
-//      the occupations of the ROW state (hamiltonian_build.py:125-131).
-//   3. connected components of that graph (hopping conserves total charge, so H
-//      is block diagonal; the padding copies of |0..0> are always isolated).
-//   4. Gershgorin pruning: a component whose lower bound min(F - sum|H_ij|)
-//      exceeds min F overall cannot hold the ground state.
-//   5. every surviving component in parallel: Lanczos from the all-ones vector
-//      (H_t <= 0 off-diagonal => the ground vector of an irreducible block is
-//      positive, so the start vector always overlaps it); at most `size` steps.
-//      The tridiagonal T lives one row per member lane.
-//   6. lowest eigenvalue of T by Laguerre's iteration from the left of the
-//      spectrum (monotone, cubic), eigenvector of T by inverse iteration with the
-//      SPD factorisation just below it.
-//   7. second Lanczos pass accumulates x = Q y (no basis storage); it replays the
-//      recurrence with the stored alpha/beta, so it needs no reductions.
-//   8. the component with the lowest eigenvalue wins; <n> = sum_m x_m^2 s_m.
-// Solving block by block is at least as accurate as one dense 32x32 eigh (no
-// rounding-level mixing of different charge sectors).
+//   A  STRUCTURE, one pixel per half-wave, one basis state per lane (qd_ground_structure):
+//      hop neighbours (states i, j couple over the adjacent pair d iff s_j - s_i = -+e_d +-e_{d+1}; with 4-bit-spaced
+//      delta codes that is a borrow-free nibble difference of 0x1F << 4q or 0xF1 << 4q), coefficients
+//      H_ij = -t_d sqrt(n_from (n_to + 1)) with the occupations of the ROW state (hamiltonian_build.py:125-131),
+//      connected components (hopping conserves the total charge, so H is block diagonal; the padding copies of
+//      |0..0> are always isolated), Gershgorin pruning (a component whose lower bound min(F - sum|H_ij|) exceeds
+//      min F cannot hold the ground state).  Every surviving component of >= 2 states becomes a TASK: its dense
+//      block is written, lower triangle packed, into the block's private slab and its offset appended to the list
+//      of its size class.
+//   B  SOLVE, one TASK per lane (qd_eig.h): Householder tridiagonalisation, Laguerre, inverse iteration; 64 lanes =
+//      64 different blocks of the same size.  (Round 2 ran Lanczos + the serial tridiagonal recurrences with one
+//      state per lane: every member lane of a component repeated the identical computation and a wave paid the
+//      maximum over its ~11 components; plain Lanczos also lost near-degenerate lowest pairs at tc >~ 1e14.)
+//   C  SELECT, one pixel per lane (qd_ground_select): the component with the lowest eigenvalue wins (ties: lowest
+//      candidate index), <n> = sum_m x_m^2 s_m, the sensor constant c0.
+// Solving block by block is at least as accurate as one dense 32x32 eigh (no rounding-level mixing of different charge
+// sectors); exactly-zero couplings do not link states, so tc == 0 gives exact integer occupations.
 #pragma once
 #include "qd_pixel.h"
+#include "qd_eig.h"
 
 #if defined(__HIPCC__)
 
 #define QD_NBMAX 14                 // a state has at most 2*(N-1) hop neighbours
-#ifndef QD_NBREG
-#define QD_NBREG 3                  // neighbour slots kept in registers for the matvecs
-#endif
+#define QD_GS_BLOCK 256
+#define QD_GS_PPB 256               // pixels per batch (4 waves x 32 iterations x 2 pixels)
+#define QD_GS_NBIN (QD_EIG_REG)     // size classes: 2 .. QD_EIG_REG states (register solver), then "larger" (memory solver)
+#define QD_LINK_NONE 0xFFFFFFFFu    // state whose component cannot hold the ground state (Gershgorin)
+#define QD_LINK_SINGLE 0xFFFFFFFEu  // isolated state that can: T = [F]
 
 // LDS-qualified volatile pointers: a plain `volatile double*` into __shared__ memory stays a generic
 // pointer (address-space inference skips volatile accesses) and every access becomes a FLAT load;
@@ -49,56 +42,60 @@ typedef volatile qd_lds_double* qd_lds_vptr;
 typedef const volatile qd_lds_double* qd_lds_cvptr;
 
 struct QdWaveLds {
-    double coef[QD_NBMAX - QD_NBREG][64];      // H_ij of neighbour slots QD_NBREG.. of lane (the first QD_NBREG live in registers)
-    unsigned char nidx[QD_NBMAX - QD_NBREG][64];
-    double buf[66];                 // publish buffer for per-component reductions; buf[64] == 0.0 (neutral slot)
-    double al[64], be[64];          // T: alpha_r / beta_r at the r-th member lane
-    double rd[64], lf[64], yv[64];  // inverse iteration: 1/d_i, l_i, y_i at member slots
-    double ib[64];                  // 1/beta_r at the r-th member lane (pass-2 replay)
-    double pv[2][16];               // per half: vpp[0..N] (cgd @ v_ext) then tc[0..N-2] at offset 9
-    short pfl[2][8];                // per half: floor(n_cont) (|n| < 2^15 by a wide margin; 16-bit keeps 4 blocks per CU within 160 KB)
+    double coef[QD_NBMAX][64];      // H_ij of neighbour slot s of lane
+    unsigned char nidx[QD_NBMAX][64];
+    double buf[64];                 // publish buffer for per-component reductions
+    double pv[2][16];               // per half: tc[0..N-2] at offset 9
+    short pfl[2][8];                // per half: floor(n_cont)
 };
+struct QdBlockLds {
+    unsigned pool_top;              // bump allocator of the block's slab (doubles)
+    unsigned cnt[QD_GS_NBIN];       // tasks per size class: [s - 2] for s <= QD_EIG_REG, last = larger
+};
+
+// The block's private scratch in HBM/L2 (one per persistent block, reused batch after batch):
+//   pool   task records: [0] lambda (out), [1] residual (out; in: the size, for the memory solver),
+//          [2 ..] packed lower triangle (in), overwritten by x[0..s-1] (out); larger blocks carry a 4 s workspace
+//          (+ a copy of the matrix in validate mode)
+//   link   per pixel and state: record offset of its component, QD_LINK_SINGLE or QD_LINK_NONE;  rank: index inside it
+//   lists  per size class: record offsets
+//   aux    per pixel: ||H||_inf (validate: scale of the residual)
+struct QdSlab {
+    double* pool; unsigned* link; unsigned char* rank; unsigned* lists; double* aux;
+};
+__host__ __device__ inline int qd_gs_list_cap(int bin) { return QD_GS_PPB * (32 / (bin + 2 > QD_EIG_REG ? QD_EIG_REG + 1 : bin + 2)); }
+__host__ __device__ inline int qd_gs_list_off(int bin) { int o = 0; for (int b = 0; b < bin; ++b) o += qd_gs_list_cap(b); return o; }
+__host__ __device__ inline int qd_gs_task_doubles(int s, bool validate) {
+    const int ne = s * (s + 1) / 2;
+    return 2 + ne + (s > QD_EIG_REG ? 4 * s + (validate ? ne : 0) : 0);
+}
+// worst case per pixel: one component of all 32 states
+__host__ __device__ inline size_t qd_gs_pool_doubles(bool validate) { return (size_t)QD_GS_PPB * (size_t)qd_gs_task_doubles(32, validate); }
+__host__ __device__ inline size_t qd_gs_slab_bytes(bool validate) {
+    size_t b = qd_gs_pool_doubles(validate) * 8;
+    b += (size_t)QD_GS_PPB * 32 * 4;                      // link
+    b += (size_t)qd_gs_list_off(QD_GS_NBIN) * 4;          // lists
+    b += (size_t)QD_GS_PPB * 8;                           // aux
+    b += (size_t)QD_GS_PPB * 32;                          // rank
+    return (b + 255) & ~(size_t)255;
+}
+__host__ __device__ inline QdSlab qd_gs_slab(unsigned char* base, bool validate) {
+    QdSlab s;
+    s.pool = (double*)base; base += qd_gs_pool_doubles(validate) * 8;
+    s.link = (unsigned*)base; base += (size_t)QD_GS_PPB * 32 * 4;
+    s.lists = (unsigned*)base; base += (size_t)qd_gs_list_off(QD_GS_NBIN) * 4;
+    s.aux = (double*)base; base += (size_t)QD_GS_PPB * 8;
+    s.rank = base;
+    return s;
+}
 
 __device__ __forceinline__ unsigned qd_half_ballot(bool p) {
     unsigned long long b = __ballot(p);
     return (unsigned)(b >> (threadIdx.x & 32));
 }
-__device__ __forceinline__ double qd_rcp(double x) {
-    double r = __builtin_amdgcn_rcp(x);
-    r = fma(fma(-x, r, 1.0), r, r);
-    r = fma(fma(-x, r, 1.0), r, r);
-    return r;
-}
-// v_rcp_f64 / v_rsq_f64 deliver 4.6e-8 / 5.2e-8 relative accuracy on gfx950, one Newton step 2e-15 / 4e-15, two steps
-// 1.1e-16 / 2.4e-16 (scripts/proto/rcp_precision.hip).  One step is enough where the result only steers an iteration
-// (Laguerre's step) and for sqrt alone, whose own correction step squares the error away.
-__device__ __forceinline__ double qd_rcp1(double x) {
-    double r = __builtin_amdgcn_rcp(x);
-    return fma(fma(-x, r, 1.0), r, r);
-}
-__device__ __forceinline__ double qd_sqrt1(double x) {           // sqrt(x), x > 0, ~1 ulp
-    double y = __builtin_amdgcn_rsq(x);
-    y = y * fma(-0.5 * x * y, y, 1.5);
-    const double s = x * y;
-    return fma(fma(-s, s, x), 0.5 * y, s);
-}
-// sqrt(x) and 1/sqrt(x) from one v_rsq_f64 + two Newton steps (x > 0); ~1 ulp
-__device__ __forceinline__ void qd_sqrt_rsqrt(double x, double& s, double& r) {
-    double y = __builtin_amdgcn_rsq(x);
-    y = y * fma(-0.5 * x * y, y, 1.5);
-    y = y * fma(-0.5 * x * y, y, 1.5);
-    r = y;
-    s = x * y;
-    s = fma(fma(-s, s, x), 0.5 * y, s);            // one correction step for sqrt
-}
 __device__ __forceinline__ double qd_half_min(double v) {
 #pragma unroll
     for (int o = 16; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o, 32));
-    return v;
-}
-__device__ __forceinline__ double qd_half_sum(double v) {
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 32);
     return v;
 }
 // wave-wide maximum, returned through readfirstlane so that the compiler knows it is uniform: loop bounds
@@ -109,57 +106,13 @@ __device__ __forceinline__ int qd_wave_max_int(int v) {
     return __builtin_amdgcn_readfirstlane(v);
 }
 
-// per-component (segment) reductions through the LDS publish buffer.  `seg` is
-// the member mask (bit b = lane b of my half), hb = 0 or 32, smax = wave-wide
-// max member count.  Summation runs over members in ascending lane order, so
-// every member gets bit-identical results.  The first 8 member slots are kept as
-// register-resident LDS indices (`QdMembers`); slots beyond the member count
-// point at the neutral element buf[64] == 0.0, so the common case (components of
-// <= 8 states) is 8 independent LDS reads with no predication.
-struct QdMembers {
-    int idx[8];          // LDS index (into buf) of member i, or 64 (neutral) if i >= size
-    unsigned rest;       // members beyond the first 8
-    int nrest_max;       // wave-wide max count of such members
-};
-
-__device__ __forceinline__ double qd_seg_sum(double v, const QdMembers& M, qd_lds_vptr buf, int hb) {
-    buf[threadIdx.x & 63] = v;
-    __builtin_amdgcn_wave_barrier();
-    double acc = 0.0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) acc += buf[M.idx[i]];
-    unsigned mm = M.rest;
-    for (int it = 0; it < M.nrest_max; ++it) {
-        if (mm) { int b = __builtin_ctz(mm); mm &= mm - 1; acc += buf[hb + b]; }
-    }
-    __builtin_amdgcn_wave_barrier();
-    return acc;
-}
-__device__ __forceinline__ double qd_seg_min(double v, const QdMembers& M, int ssz, qd_lds_vptr buf, int hb) {
-    buf[threadIdx.x & 63] = v;
-    __builtin_amdgcn_wave_barrier();
-    double acc = INFINITY;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) { const double t = buf[M.idx[i]]; acc = (i < ssz) ? fmin(acc, t) : acc; }
-    unsigned mm = M.rest;
-    for (int it = 0; it < M.nrest_max; ++it) {
-        if (mm) { int b = __builtin_ctz(mm); mm &= mm - 1; acc = fmin(acc, buf[hb + b]); }
-    }
-    __builtin_amdgcn_wave_barrier();
-    return acc;
-}
-__device__ __forceinline__ double qd_seg_max(double v, const QdMembers& M, int ssz, qd_lds_vptr buf, int hb) {
-    return -qd_seg_min(-v, M, ssz, buf, hb);
-}
-
-// One pixel per half-wave.  rec: this half's pixel record (states, their free energies from the
-// candidates kernel, v'', tunnel couplings).  On return lane m of the half holds the
-// expectation occupation of dot (m >> 2) & 7 (0 for dots >= N) and every lane the ground energy.
-// VALIDATE additionally returns (every lane) the relative residual ||H x - lam x||_2 / ||H||_inf of the
-// winning component's eigenpair -- the on-device proof that the solve converged, in every regime.
-template <int N, bool VALIDATE = false>
-__device__ void qd_ground_pixel(const QdPixelRec* __restrict__ rec, QdWaveLds& W, double* occ, double* lam_out,
-                                double* resid_out = nullptr) {
+// ---------------------------------------------------------------------------------------------------------------
+// Phase A.  rec: this half's pixel record (states, their free energies from the candidate search, tunnel couplings);
+// ps: the pixel's slot in the batch; live: false for the clamped duplicate beyond the image (nothing is emitted).
+// ---------------------------------------------------------------------------------------------------------------
+template <int N, bool VALIDATE>
+__device__ __forceinline__ void qd_ground_structure(const QdPixelRec* __restrict__ rec, bool live, int ps, QdWaveLds& W,
+                                                    QdBlockLds& S, const QdSlab& sl) {
     const int lane = threadIdx.x & 63;
     const int m = lane & 31;
     const int hb = lane & 32;
@@ -169,8 +122,7 @@ __device__ void qd_ground_pixel(const QdPixelRec* __restrict__ rec, QdWaveLds& W
     // ---- 1. my state -------------------------------------------------------
     // pixel-uniform record fields go through LDS once (keeps them out of registers)
     const int hh = hb >> 5;
-    if (m < N + 1) W.pv[hh][m] = rec->vpp[m];
-    else if (m >= 9 && m < 9 + N - 1) W.pv[hh][m] = rec->tc[m - 9];
+    if (m >= 9 && m < 9 + N - 1) W.pv[hh][m] = rec->tc[m - 9];
     if (m >= 16 && m < 16 + N) W.pfl[hh][m - 16] = (short)rec->fl[m - 16];
     __builtin_amdgcn_wave_barrier();
     const double* pvv = W.pv[hh];
@@ -182,14 +134,10 @@ __device__ void qd_ground_pixel(const QdPixelRec* __restrict__ rec, QdWaveLds& W
     ecode = (ecode | (ecode << 8)) & 0x00FF00FFu;
     ecode = (ecode | (ecode << 4)) & 0x0F0F0F0Fu;
     ecode = (ecode | (ecode << 2)) & 0x33333333u;
-    // occupation of dot i in this lane's state: floor + digit - 1 (0 for the padding lanes); decoded where it is needed,
-    // not kept in registers through the solve
-    auto occ_of = [&](int i) -> int { return valid ? (int)W.pfl[hh][i] + (int)((ecode >> (4 * (N - 1 - i))) & 3u) - 1 : 0; };
-    // F_m: the candidate kernel already evaluated the canonical energy of every kept state, and of the
-    // |0..0> padding when fewer than 32 candidates are valid (N <= 3)
-    // The diagonal enters RELATIVE to the pixel's lowest free energy: H - c I has the same eigenvectors, and without the
-    // common offset (|F| ~ 1e3..1e5 far from the ground truth, against spreads of O(1)) the three-term recurrence no
-    // longer loses ~eps |F| in every subtraction -- measured at 64x64 in the wild regime: eigen residuals 1e-8..1e-6 -> round-off.
+    // F_m: the candidate search already evaluated the canonical energy of every kept state, and of the |0..0> padding
+    // when fewer than 32 candidates are valid (N <= 3).  The diagonal enters RELATIVE to the pixel's lowest free energy:
+    // H - c I has the same eigenvectors, and the common offset (|F| ~ 1e3..1e5 far from the ground truth, against
+    // spreads of O(1)) would cost ~eps |F| in every subtraction.
     const double Fabs = rec->E[m];
     const double fshift = qd_half_min(Fabs);
     const double F = Fabs - fshift;
@@ -227,16 +175,13 @@ __device__ void qd_ground_pixel(const QdPixelRec* __restrict__ rec, QdWaveLds& W
         }
     }
     // states beyond the valid count (|0..0> padding) neither hop nor are hopped to
-    nbrmask = valid ? (nbrmask & (nvalid >= 32 ? 0xFFFFFFFFu : ((1u << nvalid) - 1u))) : 0u;
+    nbrmask = (valid && live) ? (nbrmask & (nvalid >= 32 ? 0xFFFFFFFFu : ((1u << nvalid) - 1u))) : 0u;
 #if defined(QD_ABLATE) && QD_ABLATE == 4
     nbrmask = 0;                                          // diagnostic: no hopping at all
 #endif
     const int cnt = __popc(nbrmask);
     const int maxcnt = qd_wave_max_int(cnt);
-    // the first QD_NBREG neighbour slots stay in registers for the matvecs, the rest in LDS
-    double nbc[QD_NBREG + 1]; int nbi[QD_NBREG + 1];
-#pragma unroll
-    for (int i = 0; i < QD_NBREG; ++i) { nbc[i] = 0.0; nbi[i] = m; }
+    double radius = 0.0;
     {
         unsigned rem = nbrmask;
         for (int s = 0; s < maxcnt; ++s) {
@@ -261,23 +206,20 @@ __device__ void qd_ground_pixel(const QdPixelRec* __restrict__ rec, QdWaveLds& W
                 if (prod > 0.0) sq_ = qd_sqrt1(prod);
                 c = -t * sq_;
             }
-#pragma unroll
-            for (int i = 0; i < QD_NBREG; ++i) if (i == s) { nbc[i] = c; nbi[i] = j; }
-            if (s >= QD_NBREG) { W.coef[s - QD_NBREG][lane] = c; W.nidx[s - QD_NBREG][lane] = (unsigned char)j; }
+            W.coef[s][lane] = c; W.nidx[s][lane] = (unsigned char)j;
+            radius += fabs(c);
         }
     }
 
     // ---- 3. connected components (reach masks) -----------------------------
-    unsigned seg = 1u << m;
-    if (valid) seg |= nbrmask;
+    unsigned seg = (1u << m) | nbrmask;
     for (int guard = 0; guard < 32; ++guard) {
-        unsigned nw = seg;
-#pragma unroll
-        for (int i = 0; i < QD_NBREG; ++i)
-            if (i < maxcnt) { const unsigned r2 = __shfl(seg, nbi[i], 32); if (i < cnt) nw |= r2; }
-        for (int s = QD_NBREG; s < maxcnt; ++s) {
-            const unsigned r2 = __shfl(seg, (int)W.nidx[s - QD_NBREG][lane], 32);
-            if (s < cnt) nw |= r2;
+        unsigned nw = seg, rem = nbrmask;
+        for (int s = 0; s < maxcnt; ++s) {
+            const bool has = rem != 0;
+            const int j = has ? __builtin_ctz(rem) : m;
+            rem &= rem - 1;
+            nw |= __shfl(seg, j, 32);                     // (own mask for exhausted lanes: no change)
         }
         const bool changed = nw != seg;
         seg = nw;
@@ -286,419 +228,154 @@ __device__ void qd_ground_pixel(const QdPixelRec* __restrict__ rec, QdWaveLds& W
     const int ssz = __popc(seg);
     const int r = __popc(seg & lt);                        // my index inside the component
     const int smax = qd_wave_max_int(ssz);
-    QdMembers MB;
-    {
-        unsigned mm = seg;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            MB.idx[i] = mm ? hb + __builtin_ctz(mm) : 64;
-            mm &= mm - 1;
-        }
-        MB.rest = mm;
-        MB.nrest_max = smax > 8 ? smax - 8 : 0;
-    }
 
     // ---- 4. Gershgorin pruning ---------------------------------------------
-    double radius = 0.0;
-#pragma unroll
-    for (int i = 0; i < QD_NBREG; ++i) radius += fabs(nbc[i]);
-    for (int s = QD_NBREG; s < maxcnt; ++s) radius += fabs(W.coef[s - QD_NBREG][lane]);
-    const double upper_all = 0.0;                          // = min F: the diagonal is relative to the lowest free energy
-    const double comp_lower = qd_seg_min(F - radius, MB, ssz, buf, hb);
-    const bool active = comp_lower <= upper_all;
-
-    // ---- 5. Lanczos pass 1: T ----------------------------------------------
+    // upper bound of the pixel's ground energy: min F = 0 (the diagonal is relative to the lowest free energy)
+    double comp_lower;
+    {
+        buf[lane] = F - radius;
+        __builtin_amdgcn_wave_barrier();
+        double acc = INFINITY;
+        unsigned mm = seg;
+        for (int it = 0; it < smax; ++it) {
+            if (mm) { const int b = __builtin_ctz(mm); mm &= mm - 1; acc = fmin(acc, buf[hb + b]); }
+        }
+        __builtin_amdgcn_wave_barrier();
+        comp_lower = acc;
+    }
+    const bool active = live && comp_lower <= 0.0;
 #if defined(QD_ABLATE) && QD_ABLATE == 3
-    const bool solve = false;                              // diagnostic: skip Lanczos/Laguerre/inverse iteration
+    const bool solve = false;                              // diagnostic: no tasks
 #else
     const bool solve = active && ssz > 1;
 #endif
-    double q0 = 0.0;
-    { double s_, r_; qd_sqrt_rsqrt((double)ssz, s_, r_); q0 = solve ? r_ : 0.0; }     // 1/sqrt(size), ssz >= 1
-    double q = q0, qp = 0.0, bp = 0.0, anorm = 0.0;
-    double al_mine = F, be_mine = 0.0, ib_mine = 0.0;      // singleton: T = [F]
-    int k = solve ? 0 : 1;
-    bool done = !solve;
-    const int jmax = smax;                                 // (loop bound only: the loops stop when no lane is running)
-    // The LDS rows of neighbour slots nobody uses (slots >= maxcnt) keep the Lanczos vectors q_j when every component of
-    // the wave fits: pass 2 (x = sum_j y_j q_j) then reads them back instead of replaying the recurrence with its matvecs.
-    const int nfree = (QD_NBMAX - QD_NBREG) - (maxcnt > QD_NBREG ? maxcnt - QD_NBREG : 0);
-    const bool qstash = smax <= nfree;
-    double lo_run = INFINITY;                              // Gershgorin lower bound of T, kept while its rows appear
-    for (int j = 0; j < jmax; ++j) {
-        if (!__any(!done)) break;
-        if (qstash) W.coef[(QD_NBMAX - QD_NBREG - 1) - j][lane] = q;
-        // matvec: q is published once and every neighbour's entry is one 64-bit LDS read (a 64-bit
-        // cross-lane shuffle would be two ds_bpermute each); LDS operations of a wave complete in order,
-        // so the reduction below may overwrite the buffer without another barrier
-        double w = F * q;
-        buf[lane] = q;
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int i = 0; i < QD_NBREG; ++i)
-            if (i < maxcnt) { const double qj = buf[hb + nbi[i]]; w = fma(nbc[i], qj, w); }
-        for (int s = QD_NBREG; s < maxcnt; ++s) {
-            const double qj = buf[hb + (int)W.nidx[s - QD_NBREG][lane]];
-            w = fma(W.coef[s - QD_NBREG][lane], qj, w);
-        }
-        const double a = qd_seg_sum(q * w, MB, buf, hb);
-        w = w - a * q - bp * qp;
-        const double b2 = qd_seg_sum(w * w, MB, buf, hb);
-        double b = 0.0, ib = 0.0;
-        if (b2 > 0.0) qd_sqrt_rsqrt(b2, b, ib);
-        if (!done) {
-            anorm = fmax(anorm, fmax(fabs(a), b));
-            if (r == j) { al_mine = a; be_mine = b; ib_mine = ib; }
-            k = j + 1;
-            const bool last = j + 1 >= ssz || !(b > 1e-13 * anorm);
-            lo_run = fmin(lo_run, a - bp - (last ? 0.0 : b));         // row j: alpha_j - beta_{j-1} - beta_j
-            if (last) {
-                done = true;
-                if (r == j) be_mine = 0.0;
-            } else {
-                qp = q; bp = b; q = w * ib;
-            }
-        }
-    }
-    // T is published SCALED by a power of two (exact) so that ||T|| lies in [1, 2): the minors of the Laguerre recurrences
-    // then grow by at most 5 per row and need no rescaling at all -- with tc up to 1e44 in the random-action regime the
-    // unscaled minors of a 12-row T overflowed between two rescalings (a wrong eigenvalue in a handful of pixels of the
-    // 458 752-pixel sweep of round 2).  Scale of T: ||T|| <= max_j (|alpha_j| + 2 beta_j) <= 3 anorm (the maximum Lanczos
-    // kept; component-uniform) or the Gershgorin bound kept while its rows appeared.
-    const double lo_uns = solve ? lo_run : F;
-    const double tscale_uns = fmax(fabs(lo_uns), 3.0 * anorm);
-    double tsc = 1.0, tusc = 1.0;                          // 2^-E and 2^E, E = exponent of the scale
-    {
-        const unsigned long long ef = ((unsigned long long)__double_as_longlong(tscale_uns) >> 52) & 0x7FFull;
-        if (ef != 0ull && ef < 2046ull) {
-            tsc = __longlong_as_double((long long)((2046ull - ef) << 52));
-            tusc = __longlong_as_double((long long)(ef << 52));
-        }
-    }
-    W.al[lane] = al_mine * tsc;
-    W.be[lane] = (r < k - 1) ? be_mine * tsc : 0.0;
-    W.ib[lane] = ib_mine;
-    al_mine *= tsc; be_mine *= tsc;
-    __builtin_amdgcn_wave_barrier();
-    qd_lds_cvptr al = (qd_lds_cvptr)W.al;
-    qd_lds_cvptr be = (qd_lds_cvptr)W.be;
-    const int kmax = smax;                                 // k <= component size: bound of the row loops beyond the 8 unrolled rows
 
-    // ---- 6a. lowest eigenvalue of T: Laguerre iteration from the left ----------
-    // p(x) = det(T - x) has only real roots; started left of all of them, Laguerre's
-    // iteration increases monotonically to the smallest root with cubic convergence
-    // (3-4 iterations; validated against eigvalsh over 12 decades of scale).  p, p', p''
-    // come from the three-term recurrence of the leading minors, rescaled together.
-    // Every member lane runs the same computation on the rows published in al/be.
-    double lo = lo_uns * tsc, hi = lo;                     // Gershgorin lower bound of the scaled T (T = [F] where nothing was solved)
-    const double tscale = tscale_uns * tsc;                // in [1, 2)
-    double xl = lo - (1e-3 * tscale + 1e-300);
-#if defined(QD_DEBUG_STATS)
-    int dbg_myits = 0, dbg_waveits = 0;                    // diagnostic build (scripts/solver_stats.py)
-#endif
+    // ---- 5. tasks: one record per surviving component ------------------------
+    unsigned base = 0;
+    if (solve && r == 0) {
+        base = atomicAdd(&S.pool_top, (unsigned)qd_gs_task_doubles(ssz, VALIDATE));
+        const int bin = (ssz > QD_EIG_REG ? QD_EIG_REG + 1 : ssz) - 2;
+        const unsigned pos = atomicAdd(&S.cnt[bin], 1u);
+        sl.lists[qd_gs_list_off(bin) + pos] = base;
+        if (ssz > QD_EIG_REG) sl.pool[base + 1] = (double)ssz;
+    }
+    base = (unsigned)__shfl((int)base, __builtin_ctz(seg), 32);
+    if (live) {
+        sl.link[ps * 32 + m] = solve ? base : (active ? QD_LINK_SINGLE : QD_LINK_NONE);
+        sl.rank[ps * 32 + m] = (unsigned char)r;
+        if (VALIDATE) {
+            const double hn = -qd_half_min(-(fabs(Fabs) + radius));       // ||H||_inf over the 32 states (unshifted)
+            if (m == 0) sl.aux[ps] = hn;
+        }
+    }
     {
-#if defined(QD_ABLATE) && QD_ABLATE == 1
-        bool conv = true;                                  // diagnostic: skip Laguerre
-#else
-        bool conv = k <= 1;
-#endif
-        const double dk = (double)k;
-        double sprev = 0.0;                                // previous Laguerre step (0: none yet)
-        for (int it = 0; it < 48; ++it) {
-            if (!__any(!conv)) break;
-#if defined(QD_DEBUG_STATS)
-            dbg_waveits = it + 1; if (!conv) dbg_myits = it + 1;
-#endif
-            // p, p', p'' at xl: three-term recurrences over the rows of the scaled T (|entries| <= 2: no rescaling needed).
-            // The first 8 rows use the register-resident member slots (no bit scanning).
-            double p0 = 1.0, p1 = 1.0, d0 = 0.0, d1 = 0.0, e0 = 0.0, e1 = 0.0, bprev = 0.0;
-#define QD_LAG_ROW(AL, BE, FIRST)                                                   \
-            {                                                                       \
-                const double a_ = (AL) - xl;                                        \
-                const double b2_ = bprev * bprev;                                   \
-                double p2_, d2_, e2_;                                               \
-                if (FIRST) { p2_ = a_; d2_ = -1.0; e2_ = 0.0; }                     \
-                else {                                                              \
-                    p2_ = fma(a_, p1, -(b2_ * p0));                                 \
-                    d2_ = fma(a_, d1, -(b2_ * d0)) - p1;                            \
-                    e2_ = fma(a_, e1, -(b2_ * e0)) - 2.0 * d1;                      \
-                }                                                                   \
-                p0 = p1; p1 = p2_; d0 = d1; d1 = d2_; e0 = e1; e1 = e2_;            \
-                bprev = (BE);                                                       \
-            }
-            // Unrolled rows 0..7 ping-pong between the two register sets (even rows overwrite the "older"
-            // set 0, odd rows set 1) instead of rotating p0 <- p1 <- p2: inside predicated blocks the
-            // rotation costs six 64-bit moves per row.  After an even number of rows the roles are the
-            // usual ones (set 1 = current), which is what the dynamic tail loop below relies on (only
-            // lanes with k > 8 enter it); lanes that stopped after an odd k < 8 are fixed up afterwards.
-#define QD_LAG_ROW_PP(AL, BE, FIRST, PO, PC, DO, DC, EO, EC)                        \
-            {                                                                       \
-                const double a_ = (AL) - xl;                                        \
-                const double b2_ = bprev * bprev;                                   \
-                if (FIRST) { PO = a_; DO = -1.0; EO = 0.0; }                        \
-                else {                                                              \
-                    const double pn_ = fma(a_, PC, -(b2_ * PO));                    \
-                    const double dn_ = fma(a_, DC, -(b2_ * DO)) - PC;               \
-                    const double en_ = fma(a_, EC, -(b2_ * EO)) - 2.0 * DC;         \
-                    PO = pn_; DO = dn_; EO = en_;                                   \
-                }                                                                   \
-                bprev = (BE);                                                       \
-            }
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                if (i < k) {
-                    if (i & 1) { QD_LAG_ROW_PP(al[MB.idx[i]], be[MB.idx[i]], false, p1, p0, d1, d0, e1, e0) }
-                    else       { QD_LAG_ROW_PP(al[MB.idx[i]], be[MB.idx[i]], i == 0, p0, p1, d0, d1, e0, e1) }
-                }
-            }
-#undef QD_LAG_ROW_PP
-            {
-                unsigned mm = MB.rest;
-                for (int i = 8; i < kmax; ++i) {
-                    if (i < k) {
-                        const int b = __builtin_ctz(mm); mm &= mm - 1;
-                        QD_LAG_ROW(al[hb + b], be[hb + b], false)
-                    }
-                }
-            }
-            if (k < 8 && (k & 1)) { p1 = p0; d1 = d0; e1 = e0; }      // odd row count: the current values sit in set 0
-#undef QD_LAG_ROW
-            if (!conv) {
-                if (p1 == 0.0) conv = true;
-                else {
-                    const double ip = qd_rcp1(p1);
-                    const double G = d1 * ip, E = e1 * ip;
-                    double disc = (dk - 1.0) * ((dk - 1.0) * G * G - dk * E);
-                    // the iterate needs no correctly rounded sqrt / quotient (the fixed point does not depend
-                    // on them): rsq / rcp + one Newton step (2e-15) are a quarter of the IEEE sequences' instructions
-                    double sq = 0.0;
-                    if (disc > 0.0) sq = qd_sqrt1(disc);
-                    const double den = (G < 0.0) ? G - sq : G + sq;
-                    const double xn = (den != 0.0) ? fma(-dk, qd_rcp1(den), xl) : xl;
-                    if (!(xn > xl)) conv = true;                       // monotone sequence has stalled
-                    else {
-                        const double st = xn - xl, tol = 4e-16 * fmax(fabs(xn), fabs(xl));
-                        if (st <= tol) conv = true;
-                        // cubic convergence (simple lowest root): e_next ~ C st^3 with C ~ st / sprev^3, so the
-                        // iteration after this one would only confirm; stop when that prediction, with a factor
-                        // 100 in hand, is below the tolerance.  (Linear convergence towards a cluster, st ~ 0.4
-                        // sprev, never passes the test.)
-                        const double s2 = st * st, p3 = sprev * sprev * sprev;
-                        if (100.0 * s2 * s2 <= tol * p3) conv = true;
-                        sprev = st;
-                        xl = xn;
-                    }
-                }
+        // my row of the lower triangle: couplings to members of lower rank, zeros elsewhere, F on the diagonal
+        double* row = sl.pool + base + 2 + (r * (r + 1)) / 2;
+        unsigned nrm = 0;                                  // ranks that carry a coupling
+        for (int s = 0; s < maxcnt; ++s) {
+            if (s < cnt && solve) {
+                const int j = (int)W.nidx[s][lane];
+                const int rj = __popc(seg & ((1u << j) - 1u));
+                if (rj < r) { row[rj] = W.coef[s][lane]; nrm |= 1u << rj; }
             }
         }
+        for (int c = 0; c < smax - 1; ++c)
+            if (solve && c < r && !((nrm >> c) & 1u)) row[c] = 0.0;
+        if (solve) row[r] = F;
     }
-    // component-uniform eigenvalue: T = [alpha_0] when k <= 1 (row 0 = first member)
-    const double lam = (k <= 1) ? al[hb + __builtin_ctz(seg)] : xl;      // in the scaled units of T
-    lo = (k <= 1) ? lam : xl - 2e-16 * tscale;                          // shift for the inverse iteration
-    hi = lam;
+}
 
-    double yscale = 1.0;                                   // 1 / ||y|| of the last inverse iteration
-    // ---- 6b. eigenvector of T: inverse iteration, SPD factorisation at sigma = lo
-    // (T - lo) = L D L^T.  Every member lane runs the same serial recurrences and
-    // writes identical values: rd[row i] = 1/d_i, lf[row i] = l_{i-1}, yv[row i] = y_i.
-    // Rows 0..7 are addressed through the register-resident member slots.
-    {
-        const double sig = lo;
-        const double tiny = 1e-300 + 1e-18 * fmax(fabs(lo), fabs(hi));
-        // The factorisation sweep also does the forward substitution of the first iteration.  Right-hand side e_1 (the first
-        // Lanczos vector), not ones: plain Lanczos leaves GHOST copies of a converged Ritz value in T (orthogonality of Q is
-        // lost completely once tc >~ 1e10), the copies lie closer together than any shift can tell apart, and the inverse
-        // iteration returns a mixture sum_i w_i s_i of their eigenvectors s_i.  Every copy's Ritz vector is Q s_i =
-        // (s_i1 / gamma) v (v the true vector, gamma = q_1 . v), so the mixture is coherent exactly when the weights carry
-        // the sign of s_i1: from e_1 they are w_i = s_i1 / (theta_i - sigma)^2.  From ones the signs are arbitrary, copies
-        // cancelled, and the occupations of a few random-action pixels were off by 1e-5 .. 4e-3 (eigen residual 1e-5).
-        double d = 1.0, bprev = 0.0, rdp = 1.0, zfac = 0.0;
-#define QD_FAC_ROW(SLOT, FIRST)                                                     \
-        {                                                                           \
-            double di_ = al[SLOT] - sig, z_ = 1.0;                                  \
-            if (!(FIRST)) { const double l_ = bprev * rdp; di_ = di_ - l_ * bprev; W.lf[SLOT] = l_; z_ = -(l_ * zfac); } \
-            if (!(di_ > tiny)) di_ = tiny;                                          \
-            d = di_;                                                                \
-            rdp = qd_rcp(d);                                /* 1/d_i: stored, and reused as 1/d_{i-1} by the next row */ \
-            W.rd[SLOT] = rdp;                                                       \
-            W.yv[SLOT] = z_ * rdp;                                                  \
-            zfac = z_;                                                              \
-            bprev = be[SLOT];                                                       \
-        }
+// ---------------------------------------------------------------------------------------------------------------
+// Phase B: one task per lane.  rec: the task's record in the slab.
+// ---------------------------------------------------------------------------------------------------------------
+template <int S, bool VALIDATE>
+__device__ __attribute__((noinline)) int qd_eig_task(double* rec) {
+    double lam, resid, x[S];
+    int its = 0;
+    qd_eig_lowest<S, VALIDATE>(rec + 2, lam, x, resid, VALIDATE ? &its : nullptr);
+    rec[0] = lam; rec[1] = resid;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) if (i < k) QD_FAC_ROW(MB.idx[i], i == 0)
-        {
-            unsigned mm = MB.rest;
-            for (int i = 8; i < kmax; ++i) if (i < k) { const int b = hb + __builtin_ctz(mm); mm &= mm - 1; QD_FAC_ROW(b, false) }
-        }
-#undef QD_FAC_ROW
-        __builtin_amdgcn_wave_barrier();
-        // (the normalisation of y is not a sweep of its own: the 1/||y|| of the first iteration scales the right-hand side
-        // of the second, the one of the second scales y_j where pass 2 reads it)
-        for (int iter = 0; iter < 2; ++iter) {
-            // forward  L z = rhs, then w = D^-1 z   (second iteration only: the first was done with the factorisation)
-            if (iter > 0) {
-            double zprev = 0.0;
-#define QD_FWD_ROW(SLOT, FIRST)                                                     \
-            {                                                                       \
-                const double rhs_ = W.yv[SLOT] * yscale;                            \
-                const double z_ = (FIRST) ? rhs_ : rhs_ - W.lf[SLOT] * zprev;       \
-                W.yv[SLOT] = z_ * W.rd[SLOT];                                       \
-                zprev = z_;                                                         \
-            }
-#pragma unroll
-            for (int i = 0; i < 8; ++i) if (i < k) QD_FWD_ROW(MB.idx[i], i == 0)
-            {
-                unsigned mm = MB.rest;
-                for (int i = 8; i < kmax; ++i) if (i < k) { const int b = hb + __builtin_ctz(mm); mm &= mm - 1; QD_FWD_ROW(b, false) }
-            }
-#undef QD_FWD_ROW
-            __builtin_amdgcn_wave_barrier();
-            }
-            // backward  L^T y = w : y_i = w_i - l_i y_{i+1}; rows k-1 .. 0
-            double ynext = 0.0, lnext = 0.0, nrm = 0.0;
-#define QD_BWD_ROW(SLOT, IDX)                                                       \
-            {                                                                       \
-                const double y_ = W.yv[SLOT] - lnext * ynext;   /* lnext = l_i (0 for the last row) */ \
-                W.yv[SLOT] = y_;                                                    \
-                nrm = fma(y_, y_, nrm);                                             \
-                ynext = y_;                                                         \
-                lnext = ((IDX) > 0) ? W.lf[SLOT] : 0.0;          /* l_{i-1} */      \
-            }
-            {
-                // rows >= 8 first (descending), dropping member bits beyond row k-1
-                unsigned m3 = MB.rest;
-                for (int i = ssz; i > k && i > 8; --i) m3 &= ~(1u << (31 - __builtin_clz(m3)));
-                for (int i = kmax - 1; i >= 8; --i) if (i < k) { const int b = 31 - __builtin_clz(m3); m3 &= ~(1u << b); QD_BWD_ROW(hb + b, i) }
-            }
-#pragma unroll
-            for (int i = 7; i >= 0; --i) if (i < k) QD_BWD_ROW(MB.idx[i], i)
-#undef QD_BWD_ROW
-            __builtin_amdgcn_wave_barrier();
-            double inv = 1.0, sn_ = 0.0;
-            if (nrm > 0.0) qd_sqrt_rsqrt(nrm, sn_, inv);          // 1/sqrt by rsq + Newton (no correctly rounded norm needed)
-            yscale = inv;
-        }
-    }
-
-    // ---- 7. Lanczos pass 2: x = sum_j y_j q_j -------------------------------
-    // The recurrence is replayed with the alpha_j / beta_j stored by pass 1 (same
-    // operations, same bits as pass 1, without its two reductions per step).
-    double x = solve ? 0.0 : 1.0;
-    {
-        double q2 = q0, qp2 = 0.0, bp2 = 0.0;
-#if defined(QD_ABLATE) && QD_ABLATE == 2
-        bool done2 = true;                                 // diagnostic: skip pass 2
-#else
-        bool done2 = !solve;
+    for (int i = 0; i < S; ++i) rec[2 + i] = x[i];
+    return its;
+}
+#if defined(QD_DEBUG_DUMP)
+__device__ int qd_dbg_flag = 0;
 #endif
-        unsigned mm = seg;
-        if (qstash) {
-            // the Lanczos vectors are still in LDS: no recurrence to replay
-            for (int j = 0; j < jmax; ++j) {
-                if (!__any(!done2)) break;
-                if (!done2) {
-                    const int bb = __builtin_ctz(mm); mm &= mm - 1;
-                    x = fma(W.yv[hb + bb] * yscale, W.coef[(QD_NBMAX - QD_NBREG - 1) - j][lane], x);
-                    if (j + 1 >= k) done2 = true;
-                }
-            }
-        }
-        for (int j = 0; j < jmax; ++j) {
-            if (!__any(!done2)) break;
-            double yj = 0.0, a = 0.0, b = 0.0, ib = 0.0;
-            if (!done2) { const int bb = __builtin_ctz(mm); mm &= mm - 1; yj = W.yv[hb + bb] * yscale; a = al[hb + bb] * tusc; b = be[hb + bb] * tusc; ib = W.ib[hb + bb]; }
-            double w = F * q2;
-            buf[lane] = q2;
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int i = 0; i < QD_NBREG; ++i)
-                if (i < maxcnt) { const double qj = buf[hb + nbi[i]]; w = fma(nbc[i], qj, w); }
-            for (int s = QD_NBREG; s < maxcnt; ++s) {
-                const double qj = buf[hb + (int)W.nidx[s - QD_NBREG][lane]];
-                w = fma(W.coef[s - QD_NBREG][lane], qj, w);
-            }
-            __builtin_amdgcn_wave_barrier();
-            w = w - a * q2 - bp2 * qp2;
-            if (!done2) {
-                x = fma(yj, q2, x);
-                if (j + 1 >= k) done2 = true;
-                else { qp2 = q2; bp2 = b; q2 = w * ib; }       // same operands as pass 1: same bits
-            }
-        }
+template <bool VALIDATE>
+__device__ __attribute__((noinline)) int qd_eig_task_mem(double* rec) {
+    const int s = (int)rec[1];
+    const int ne = s * (s + 1) / 2;
+    double* M = rec + 2;
+    double* work = M + ne;
+    double* copy = VALIDATE ? work + 4 * s : nullptr;
+    if (VALIDATE) for (int e = 0; e < ne; ++e) copy[e] = M[e];
+    double lam, resid;
+    int its = 0;
+    qd_eig_lowest_mem(s, M, work, copy, lam, resid, VALIDATE ? &its : nullptr);
+#if defined(QD_DEBUG_DUMP)
+    if (VALIDATE && !(resid == resid) && atomicAdd(&qd_dbg_flag, 1) == 0) {
+        printf("NaN task s=%d lam=%.17g its=%d lane=%d\n", s, lam, its, (int)(threadIdx.x & 63));
+        for (int i = 0; i < s; ++i) { printf(" row %d:", i); for (int j = 0; j <= i; ++j) printf(" %.17g", copy[i * (i + 1) / 2 + j]); printf("\n"); }
+        printf(" al:"); for (int i = 0; i < s; ++i) printf(" %.6e", work[i]);
+        printf("\n be:"); for (int i = 0; i < s; ++i) printf(" %.6e", work[s + i]);
+        printf("\n y:"); for (int i = 0; i < s; ++i) printf(" %.6e", work[3 * s + i]);
+        printf("\n");
     }
-    if (solve) {
-        const double nx = qd_seg_sum(x * x, MB, buf, hb);
-        double snx = 0.0, inx = 1.0;
-        if (nx > 0.0) qd_sqrt_rsqrt(nx, snx, inx);
-        x = x * inx;
-    }
+#endif
+    rec[0] = lam; rec[1] = resid;
+    for (int i = 0; i < s; ++i) M[i] = work[3 * s + i];
+    return its;
+}
 
-    // ---- 8. pick the lowest component, expectation occupations --------------
-    const double mylam = active ? lam * tusc : INFINITY;   // back to energy units (exact)
-    const double best = qd_half_min(mylam);
-    // tie between components (exactly equal energies): the state with the lowest candidate
+// ---------------------------------------------------------------------------------------------------------------
+// Phase C: one pixel per lane.  Returns the occupations, the ground energy (absolute) and, with VALIDATE, the
+// relative residual ||H x - lam x||_2 / ||H||_inf of the winning component's eigenpair.
+// ---------------------------------------------------------------------------------------------------------------
+template <int N, bool VALIDATE>
+__device__ __forceinline__ void qd_ground_select(const QdPixelRec* __restrict__ rec, int ps, const QdSlab& sl,
+                                                 double* occ, double& lam_out, double& resid_out) {
+    const unsigned* link = sl.link + ps * 32;
+    const unsigned char* rank = sl.rank + ps * 32;
+    const int nvalid = rec->nvalid;
+    double fshift = INFINITY;
+    for (int m = 0; m < QD_K; ++m) fshift = fmin(fshift, rec->E[m]);
+    // the lowest component; tie between components (exactly equal energies): the state with the lowest candidate
     // index wins -- the reference order puts it first -- independent of the buffer order
-    unsigned key = (mylam == best) ? (valid ? code : 0xFFFFFFFEu) : 0xFFFFFFFFu;
-    unsigned kmin = key;
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) { const unsigned t = (unsigned)__shfl_xor((int)kmin, o, 32); kmin = t < kmin ? t : kmin; }
-    const unsigned win = qd_half_ballot(key == kmin);
-    const int wroot = __builtin_ctz(win);
-    const unsigned wseg = __shfl(seg, wroot, 32);
-    const double p = ((wseg >> m) & 1u) ? x * x : 0.0;
-    if constexpr (VALIDATE) {
-        const bool mine = ((wseg >> m) & 1u) != 0;
-        const double xm = mine ? x : 0.0;
-        double hx = F * xm;
-        buf[lane] = xm;
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int i = 0; i < QD_NBREG; ++i)
-            if (i < maxcnt) { const double xj = buf[hb + nbi[i]]; hx = fma(nbc[i], xj, hx); }
-        for (int s = QD_NBREG; s < maxcnt; ++s) {
-            const double xj = buf[hb + (int)W.nidx[s - QD_NBREG][lane]];
-            hx = fma(W.coef[s - QD_NBREG][lane], xj, hx);
-        }
-        __builtin_amdgcn_wave_barrier();
-        const double rr = mine ? hx - best * xm : 0.0;
-        const double r2 = qd_half_sum(rr * rr);
-        const double hn = -qd_half_min(-(fabs(Fabs) + radius));       // ||H||_inf over the 32 states (unshifted)
-        *resid_out = sqrt(r2) / (hn > 0.0 ? hn : 1.0);
-#if defined(QD_DEBUG_STATS)
-        // diagnostic build (-DQD_DEBUG_STATS, scripts/solver_stats.py): the residual slot carries packed solver statistics instead:
-        // Laguerre iterations of the wave + 1e2 * those of the winning component + 1e4 * rows of the wave + 1e6 * rows of the
-        // winner + 1e8 * lanes in solved components + 1e10 * largest solved component
-        *resid_out = (double)dbg_waveits + 1e2 * (double)__shfl(dbg_myits, wroot, 32) + 1e4 * (double)kmax + 1e6 * (double)__shfl(k, wroot, 32)
-                   + 1e8 * (double)__popc(qd_half_ballot(solve)) + 1e10 * (double)-qd_half_min(solve ? -(double)ssz : 0.0);
-#endif
+    double best = INFINITY; unsigned bestkey = 0xFFFFFFFFu, wl = QD_LINK_NONE; int bm = 0;
+    for (int m = 0; m < QD_K; ++m) {
+        const unsigned lk = link[m];
+        double lam = INFINITY;
+        if (lk == QD_LINK_SINGLE) lam = rec->E[m] - fshift;
+        else if (lk != QD_LINK_NONE) lam = sl.pool[lk];
+        const unsigned key = (m < nvalid) ? (unsigned)rec->idx[m] : 0xFFFFFFFEu;
+        const bool better = (lam < best) | ((lam == best) & (key < bestkey));
+        if (better) { best = lam; bestkey = key; wl = lk; bm = m; }
     }
-    // <n_i> = sum_m p_m n_m[i] for all dots at once by a reduce-scatter butterfly: each exchange halves
-    // the number of partial sums a lane carries (4 + 2 + 1 exchanges), two more finish the single sum
-    // left -- 9 cross-lane exchanges instead of 5 per dot.  Lane m ends up with dot (m >> 2) & 7.
-    double v[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = (i < N) ? p * (double)occ_of(i) : 0.0;
-    {
-        const bool b4 = (m & 16) != 0, b3 = (m & 8) != 0, b2 = (m & 4) != 0;
-        double w4[4], w2[2];
+    for (int i = 0; i < N; ++i) occ[i] = 0.0;
+    int fl[N];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const double send = b4 ? v[j] : v[j + 4], keep = b4 ? v[j + 4] : v[j];
-            w4[j] = keep + __shfl_xor(send, 16, 32);
+    for (int i = 0; i < N; ++i) fl[i] = rec->fl[i];
+    for (int m = 0; m < QD_K; ++m) {
+        const bool member = (wl == QD_LINK_SINGLE) ? (m == bm) : (link[m] == wl);
+        if (member) {
+            double x = 1.0;
+            if (wl != QD_LINK_SINGLE) x = sl.pool[wl + 2 + rank[m]];
+            const double p = x * x;
+            if (m < nvalid) {                              // (the padding lanes are |0..0>)
+                const unsigned code = (unsigned)rec->idx[m];
+#pragma unroll
+                for (int i = 0; i < N; ++i)
+                    occ[i] = fma(p, (double)(fl[i] + (int)((code >> (2 * (N - 1 - i))) & 3u) - 1), occ[i]);
+            }
         }
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const double send = b3 ? w4[j] : w4[j + 2], keep = b3 ? w4[j + 2] : w4[j];
-            w2[j] = keep + __shfl_xor(send, 8, 32);
-        }
-        const double send = b2 ? w2[0] : w2[1], keep = b2 ? w2[1] : w2[0];
-        double w1 = keep + __shfl_xor(send, 4, 32);
-        w1 += __shfl_xor(w1, 2, 32);
-        w1 += __shfl_xor(w1, 1, 32);
-        *occ = w1;
     }
-    *lam_out = best + fshift;
+    lam_out = best + fshift;
+    resid_out = 0.0;
+    if (VALIDATE) {
+        const double hn = sl.aux[ps];
+        if (wl != QD_LINK_SINGLE && wl != QD_LINK_NONE) resid_out = sl.pool[wl + 1] / (hn > 0.0 ? hn : 1.0);
+    }
 }
 
 #endif  // __HIPCC__

@@ -2,7 +2,7 @@
 //
 //   qd_k_actions     a2, a3   one thread per env
 //   qd_k_candidates  a5, a8, a9, a10   one pixel per lane, exact k-best search
-//   qd_k_ground      a11-a13, a15      one pixel per half-wave (qd_groundstate.h)
+//   qd_k_ground      a11-a13, a15      structure per half-wave -> dense tasks per lane -> selection per lane (qd_groundstate.h)
 //   qd_k_percentile  a17 (exact 0.5 / 99.5 percentiles, radix select)
 //   qd_k_write_obs   a17, a22 normalise + global / per-agent images + voltages
 //   qd_k_update      a19, a20, a21     Kalman, VGM (SVD pseudo-inverse), ground truth
@@ -171,7 +171,7 @@ template <int N>
 __global__ void __launch_bounds__(QD_CAND_BLOCK, QD_CAND_WAVES)
 qd_k_candidates(const int* __restrict__ env_ids, int env_base, int R, const double* __restrict__ params,
                 const double* __restrict__ state, QdPixelRec* __restrict__ recs, int sort_output, int noise_flags,
-                int only_flagged, const unsigned char* __restrict__ redo_flags) {
+                int only_flagged) {
     constexpr int G = N + 1, NB = N - 1, V = 2 * N;
     const QdLayout L = qd_layout(N);
     const int slot = blockIdx.z;
@@ -200,7 +200,6 @@ qd_k_candidates(const int* __restrict__ env_ids, int env_base, int R, const doub
     QdPixelRec* rec = recs + ((size_t)slot * (N - 1) + ch) * P + p;
     // second pass behind the tile search (qd_tile.h): only the pixels it left to the exact per-pixel search
     if (only_flagged == 1 && rec->nvalid != QD_T_REDO) return;
-    if (only_flagged == 2 && !redo_flags[((size_t)slot * (N - 1) + ch) * P + p]) return;
     double vd[N], ncont[N], isa;
     {
         double v_ext[V], vpp[G], tc[NB];
@@ -243,78 +242,117 @@ qd_k_candidates(const int* __restrict__ env_ids, int env_base, int R, const doub
 }
 
 // ---------------------------------------------------------------------------
-// a11-a13 + a15: one pixel per half-wave.  grid = (ceil(P/PPB), C, n_env).
+// a11-a13 + a15: PERSISTENT blocks, each working through batches of QD_GS_PPB pixels of one (env, channel) image in
+// three phases (qd_groundstate.h): A structure (one pixel per half-wave, one state per lane) -> tasks in the block's
+// private slab, B dense lowest eigenpair (one task per lane, size classes), C selection + occupations + sensor constant
+// (one pixel per lane).  grid = min(batches, resident blocks); slabs: one per block (qd_gs_slab_bytes).
+// stats (validate mode, 16 counters at stats[16..]): tasks, sum of Laguerre iterations, wave tiles, sum of the tiles'
+// maxima, then tasks per size class (2..8, larger).
 // ---------------------------------------------------------------------------
-#define QD_GS_BLOCK 256
-#define QD_GS_PPB 64            // pixels per block: 8 half-waves x 8 pixels
-
 #ifndef QD_GS_WAVES
-#define QD_GS_WAVES 4            // <= 128 VGPRs (no spills since the LDS pointers are address-space qualified) and 4 x 40 896 B of LDS per CU
+#define QD_GS_WAVES 2            // waves per SIMD the register budget is set for
 #endif
 template <int N, bool VALIDATE = false>
 __global__ void __launch_bounds__(QD_GS_BLOCK, QD_GS_WAVES)
-qd_k_ground(const int* __restrict__ env_ids, int env_base, int R, const double* __restrict__ params,
+qd_k_ground(const int* __restrict__ env_ids, int env_base, int n_env, int R, const double* __restrict__ params,
             const QdPixelRec* __restrict__ recs, double* __restrict__ zraw, double* __restrict__ occ_out,
-            const double* __restrict__ state, int noise_flags, double* __restrict__ eig_out = nullptr,
-            const unsigned char* __restrict__ redo_flags = nullptr) {
-    constexpr int G = N + 1;
+            const double* __restrict__ state, int noise_flags, double* __restrict__ eig_out,
+            unsigned char* __restrict__ slabs, unsigned long long* __restrict__ stats) {
+    constexpr int G = N + 1, C = N - 1;
     const QdLayout L = qd_layout(N);
-    const int slot = blockIdx.z;
-    const int e = env_ids ? env_ids[env_base + slot] : env_base + slot;
-    const int ch = blockIdx.y;
     const int P = R * R;
     __shared__ QdWaveLds sW[QD_GS_BLOCK / 64];
-    const double* par = params + (size_t)e * L.size;
-    if (threadIdx.x < QD_GS_BLOCK / 64) { sW[threadIdx.x].buf[64] = 0.0; sW[threadIdx.x].buf[65] = 0.0; }
-    __syncthreads();
-    const int half = threadIdx.x >> 5;                       // 0..7
-    QdWaveLds& W = sW[threadIdx.x >> 6];
-    const double* st = state + (size_t)e * L.s_size;
-    if (qd_radial_replaced(par, st, L, ch, noise_flags)) return;   // qd_k_sensor writes pure noise
-    const QdPixelRec* rbase = recs + ((size_t)slot * (N - 1) + ch) * P;
-    const int p0 = blockIdx.x * QD_GS_PPB;
-    for (int it = 0; it < QD_GS_PPB / 8; ++it) {
-        const int p = p0 + it * 8 + half;
-        // both halves of a wave run in lock step: clamp instead of exiting
-        const int pc = p < P ? p : P - 1;
-        if (p0 + it * 8 >= P) break;                         // uniform for the block
-        const QdPixelRec* rec = rbase + pc;
-        // behind the fused tile kernel only the pixels it handed over are solved here (both halves of a wave run in
-        // lock step: the wave skips when neither of its two pixels is flagged, results are written per pixel)
-        bool mine = true;
-        if (redo_flags) {
-            mine = p < P && redo_flags[((size_t)slot * (N - 1) + ch) * P + pc] != 0;
-            if (!__any(mine)) continue;
+    __shared__ QdBlockLds sB;
+    const QdSlab sl = qd_gs_slab(slabs + (size_t)blockIdx.x * qd_gs_slab_bytes(VALIDATE), VALIDATE);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    QdWaveLds& W = sW[wave];
+    const int nb = (P + QD_GS_PPB - 1) / QD_GS_PPB;
+    const long total = (long)n_env * C * nb;
+    for (long batch = blockIdx.x; batch < total; batch += gridDim.x) {
+        const int slot = (int)(batch / ((long)C * nb));
+        const int rem = (int)(batch - (long)slot * C * nb);
+        const int ch = rem / nb, p0 = (rem - ch * nb) * QD_GS_PPB;
+        const int e = env_ids ? env_ids[env_base + slot] : env_base + slot;
+        const double* par = params + (size_t)e * L.size;
+        const double* st = state + (size_t)e * L.s_size;
+        if (qd_radial_replaced(par, st, L, ch, noise_flags)) continue;   // qd_k_sensor writes pure noise (block-uniform)
+        const QdPixelRec* rbase = recs + ((size_t)slot * C + ch) * P;
+        if (threadIdx.x <= QD_GS_NBIN) { if (threadIdx.x == 0) sB.pool_top = 0; else sB.cnt[threadIdx.x - 1] = 0; }
+        __syncthreads();
+        // ---- A: structure, 2 pixels per wave and iteration ----
+        for (int it = 0; it < QD_GS_PPB / 8; ++it) {
+            const int ps = wave * (QD_GS_PPB / 4) + it * 2 + (lane >> 5);
+            if (p0 + wave * (QD_GS_PPB / 4) + it * 2 >= P) break;                 // uniform for the wave
+            const int p = p0 + ps;
+            // both halves of a wave run in lock step: clamp instead of exiting
+            const int pc = p < P ? p : P - 1;
+            qd_ground_structure<N, VALIDATE>(rbase + pc, p < P, ps, W, sB, sl);
         }
-        double occ, lam, resid = 0.0;
-        qd_ground_pixel<N, VALIDATE>(rec, W, &occ, &lam, &resid);
-        if constexpr (VALIDATE) {
-            // [B][C][P][2]: ground energy of the kept-state Hamiltonian and the relative residual of the eigenpair
-            if (eig_out && (threadIdx.x & 31) == 0 && p < P && mine) {
-                double* eo = eig_out + (((size_t)e * (N - 1) + ch) * P + p) * 2;
-                eo[0] = lam; eo[1] = resid;
-            }
-        }
+        __syncthreads();
+        // ---- B: one task per lane, tiles of 64 tasks of one size class dealt round-robin to the 4 waves ----
         {
-            // hand the sensor stage (qd_k_sensor) the pixel's constant c0 = 2 b + a (2 (Ns - v''_s) + 1):
-            // F_{k+1} - F_k = c0 + 2 a (k + eta)   (closed form of the reference's energy differences).
-            // Lane m holds <n_i> of dot i = (m >> 2) & 7: b = sum_i A[N][i] (<n_i> - v''_i) is three more exchanges.
-            const int m = threadIdx.x & 31;
-            const int i = (m >> 2) & 7;
-            const double* pvv = W.pv[(threadIdx.x >> 5) & 1];
-            double b = (i < N) ? par[L.cdd_inv + N * G + i] * (occ - pvv[i]) : 0.0;
-            b += __shfl_xor(b, 4, 32);
-            b += __shfl_xor(b, 8, 32);
-            b += __shfl_xor(b, 16, 32);
-            if (m == 0 && p < P && mine) {
-                const double vs = pvv[N];
-                const double Ns = rint(vs);                             // np.round: half to even
-                const double a = par[L.cdd_inv + N * G + N];
-                zraw[((size_t)e * (N - 1) + ch) * P + p] = 2.0 * b + a * (2.0 * (Ns - vs) + 1.0);
+            int tbase = 0;
+#pragma unroll
+            for (int bin = 0; bin < QD_GS_NBIN; ++bin) {
+                const int nt = (int)sB.cnt[bin];
+                const int ntile = (nt + 63) >> 6;
+                const unsigned* list = sl.lists + qd_gs_list_off(bin);
+                for (int t = 0; t < ntile; ++t) {
+                    if (((tbase + t) & 3) != wave) continue;
+                    const int idx = t * 64 + lane;
+                    int its = 0;
+                    if (idx < nt) {
+                        double* trec = sl.pool + list[idx];
+                        if (bin == 0) its = qd_eig_task<2, VALIDATE>(trec);
+                        if (bin == 1) its = qd_eig_task<3, VALIDATE>(trec);
+                        if (bin == 2) its = qd_eig_task<4, VALIDATE>(trec);
+                        if (bin == 3) its = qd_eig_task<5, VALIDATE>(trec);
+                        if (bin == 4) its = qd_eig_task<6, VALIDATE>(trec);
+                        if (bin == 5) its = qd_eig_task<7, VALIDATE>(trec);
+                        if (bin == 6) its = qd_eig_task<8, VALIDATE>(trec);
+                        if (bin == 7) its = qd_eig_task_mem<VALIDATE>(trec);
+                    }
+                    if (VALIDATE && stats) {
+                        int sum = its, mx = its;
+#pragma unroll
+                        for (int o = 32; o > 0; o >>= 1) { sum += __shfl_xor(sum, o, 64); mx = max(mx, __shfl_xor(mx, o, 64)); }
+                        if (lane == 0) {
+                            const int here = nt - t * 64 < 64 ? nt - t * 64 : 64;
+                            atomicAdd(&stats[16], (unsigned long long)here); atomicAdd(&stats[17], (unsigned long long)sum);
+                            atomicAdd(&stats[18], 1ull); atomicAdd(&stats[19], (unsigned long long)mx);
+                            atomicAdd(&stats[20 + bin], (unsigned long long)here);
+                        }
+                    }
+                }
+                tbase += ntile;
             }
-            if (occ_out && (m & 3) == 0 && i < N && p < P && mine)
-                occ_out[(((size_t)e * (N - 1) + ch) * P + p) * N + i] = occ;
         }
+        __syncthreads();
+        // ---- C: one pixel per lane ----
+        {
+            const int ps = threadIdx.x, p = p0 + ps;
+            if (p < P) {
+                const QdPixelRec* rec = rbase + p;
+                double occ[N], lam, resid;
+                qd_ground_select<N, VALIDATE>(rec, ps, sl, occ, lam, resid);
+                const size_t gp = ((size_t)e * C + ch) * P + p;
+                // hand the sensor stage (qd_k_sensor) the pixel's constant c0 = 2 b + a (2 (Ns - v''_s) + 1):
+                // F_{k+1} - F_k = c0 + 2 a (k + eta)   (closed form of the reference's energy differences),
+                // b = sum_i A[N][i] (<n_i> - v''_i)
+                double b = 0.0;
+#pragma unroll
+                for (int i = 0; i < N; ++i) b = fma(par[L.cdd_inv + N * G + i], occ[i] - rec->vpp[i], b);
+                const double vs = rec->vpp[N];
+                const double Ns = rint(vs);                                 // np.round: half to even
+                zraw[gp] = 2.0 * b + par[L.cdd_inv + N * G + N] * (2.0 * (Ns - vs) + 1.0);
+                if (occ_out) {
+#pragma unroll
+                    for (int i = 0; i < N; ++i) occ_out[gp * N + i] = occ[i];
+                }
+                if (VALIDATE && eig_out) { eig_out[gp * 2] = lam; eig_out[gp * 2 + 1] = resid; }
+            }
+        }
+        __syncthreads();                                     // the slab and the counters are reused by the next batch
     }
 }
 

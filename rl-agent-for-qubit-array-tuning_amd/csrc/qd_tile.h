@@ -35,7 +35,6 @@ struct QdTileLds {
     union {
         struct { double pn[2][QD_T_FCAP]; uint32_t code[2][QD_T_FCAP]; } f;      // frontier ping-pong
         struct { double e[QD_K][64]; uint16_t id[QD_K][64]; } k;                   // per-lane kept sets
-        struct { double q[14][64]; double tl[QD_MAXN][64]; } g;                      // ground phase (QdTileGroundVec)
     } u;
     double sD[QD_T_SCAP], sa[QD_T_SCAP], sb[QD_T_SCAP];
     uint32_t scode[QD_T_SCAP];
@@ -79,11 +78,6 @@ __device__ __forceinline__ double qd_plane_min(double a, double b, double x0, do
     return fmin(x0 * a, x1 * a) + fmin(y0 * b, y1 * b);
 }
 
-#include "qd_tile_ground.h"     // the ground phase of MODE 1 (needs QdTileLds)
-
-template <int MODE> struct QdTileGroundHolder { QdTileGroundLds g; };
-template <> struct QdTileGroundHolder<0> { int unused; };
-
 // Partial sums of one lattice point given as nibble code (dot j in nibble N-1-j, digit = c_j - lo_j):
 //   pn = sum_i [t_i^2 + g_i x_i],  x = c - m,  t_i = sum_{j<=i} U[j][i] x_j       (= E(c) - E(m))
 //   pa = lamx . (c - cg),  pb = lamy . (c - cg)
@@ -109,18 +103,14 @@ __device__ __forceinline__ void qd_tile_point(const QdTileLds& T, const double* 
 // ---------------------------------------------------------------------------------------------
 // grid = (tiles, C, n_env), block = 64 (one wavefront = one 8x8 pixel tile)
 // stats (optional, 16 counters): tiles, tiles redone whole, lanes redone, sum of |S|, lanes redone for < 32 valid
-// states in S; [8 + reason]: tiles redone by reason (1 ranges, 2 seeds, 3 frontier overflow, 4 too few leaves, 5 |S|,
-// 6 ground phase: component too large / too many structures)
+// states in S; [8 + reason]: tiles redone by reason (1 ranges, 2 seeds, 3 frontier overflow, 4 too few leaves, 5 |S|)
 // ---------------------------------------------------------------------------------------------
-// MODE 0: candidate search only, one QdPixelRec per pixel for qd_k_ground.  MODE 1: fused -- the ground state
-// follows in the same wave (qd_tile_ground.h), the kernel writes the sensor constant c0 into zraw (and, with
-// VALIDATE, occupations / eigen pair / records); pixels it cannot finish are marked in `redo` for the per-pixel kernels.
-template <int N, int MODE, bool VALIDATE>
+// Writes one QdPixelRec per pixel for the ground-state kernel (qd_k_ground).
+template <int N>
 __global__ void __launch_bounds__(64)
 qd_k_tile(const int* __restrict__ env_ids, int env_base, int R, const double* __restrict__ params,
           const double* __restrict__ state, QdPixelRec* __restrict__ recs, int sort_output, int noise_flags,
-          unsigned long long* __restrict__ stats, double* __restrict__ zraw, double* __restrict__ occ_out,
-          double* __restrict__ eig_out, unsigned char* __restrict__ redo_flags) {
+          unsigned long long* __restrict__ stats) {
     constexpr int G = N + 1, NB = N - 1, V = 2 * N;
     const QdLayout L = qd_layout(N);
     const int slot = blockIdx.z;
@@ -135,7 +125,6 @@ qd_k_tile(const int* __restrict__ env_ids, int env_base, int R, const double* __
     const int x = px < R ? px : R - 1, y = py < R ? py : R - 1;          // lanes off the image repeat an edge pixel
     const int p = y * R + x;
     __shared__ QdTileLds T;
-    __shared__ QdTileGroundHolder<MODE> GdH;                                   // hop table etc. (MODE 1 only)
     const double* spar = params + (size_t)e * L.size;
     const double* sst = state + (size_t)e * L.s_size;
     if (qd_radial_replaced(spar, sst, L, ch, noise_flags)) return;        // image will be pure noise: nothing to solve
@@ -149,7 +138,7 @@ qd_k_tile(const int* __restrict__ env_ids, int env_base, int R, const double* __
     {
         double v_ext[V];
         qd_pixel_voltages<N>(spar, sst, ch, R, x, y, v_ext, vpp, tc);
-        if (inside && recs) {
+        if (inside) {
 #pragma unroll
             for (int i = 0; i < G; ++i) rec->vpp[i] = vpp[i];
 #pragma unroll
@@ -485,9 +474,8 @@ qd_k_tile(const int* __restrict__ env_ids, int env_base, int R, const double* __
         if (fail) { atomicAdd(&stats[1], 1ull); atomicAdd(&stats[8 + why], 1ull); }
         atomicAdd(&stats[3], (unsigned long long)nS);
     }
-    const size_t pix_index = ((size_t)slot * (N - 1) + ch) * P + p;          // position in the chunk-relative scratch arrays
-    if (fail) {                                                            // the whole tile goes to the exact per-pixel kernels
-        if (inside) { if (MODE == 1) redo_flags[pix_index] = 1; else rec->nvalid = QD_T_REDO; }
+    if (fail) {                                                            // the whole tile goes to the exact per-pixel search
+        if (inside) rec->nvalid = QD_T_REDO;
         return;
     }
 
@@ -547,20 +535,11 @@ qd_k_tile(const int* __restrict__ env_ids, int env_base, int R, const double* __
         const unsigned long long rm = __ballot(redo && inside), rc = __ballot(count < QD_K && inside);
         if (lane == 0 && rm) { atomicAdd(&stats[2], (unsigned long long)__builtin_popcountll(rm)); atomicAdd(&stats[4], (unsigned long long)__builtin_popcountll(rc)); }
     }
-    if (MODE == 0) {
-        if (!inside) return;
-        if (redo) { rec->nvalid = QD_T_REDO; return; }
-    }
-    const bool alive = inside && !redo;
-    // MODE 1: the kept set as a bit mask over S and the lowest kept energy, before the union area is reused
-    QdMask256 KM; KM.w[0] = KM.w[1] = KM.w[2] = KM.w[3] = 0ull;
-    double emin = INFINITY;
-    if (MODE == 1 && alive) {
-        for (int k = 0; k < QD_K; ++k) { qd_m_set(KM, qd_s_logical((int)T.u.k.id[k][lane], nSfront)); emin = fmin(emin, T.u.k.e[k][lane]); }
-    }
+    if (!inside) return;
+    if (redo) { rec->nvalid = QD_T_REDO; return; }
 
-    // ---- 7. the record (MODE 0 always; MODE 1 only when records are kept, i.e. validate mode) --------------------
-    if (recs && alive) {
+    // ---- 7. the record ---------------------------------------------------------------------------------------
+    {
     // reference index: digit = c - floor + 1 in base 4, dot 0 most significant
     uint32_t off = 0;                                                         // lo - fl + 1 per dot, biased by +8 in nibbles
 #pragma unroll
@@ -610,38 +589,6 @@ qd_k_tile(const int* __restrict__ env_ids, int env_base, int R, const double* __
 #pragma unroll
     for (int i = 0; i < N; ++i) rec->fl[i] = fl[i];
     rec->nvalid = QD_K;
-    }
-    if constexpr (MODE == 1) {
-        // ---- 8. ground state, one pixel per lane ------------------------------------------------------------
-        __builtin_amdgcn_wave_barrier();
-        QdTileGroundLds& Gd = GdH.g;
-        QdTileGroundVec& Vv = *reinterpret_cast<QdTileGroundVec*>(&T.u);
-        double occ[N], lam = 0.0, resid = 0.0;
-#if defined(QD_TILE_ABLATE) && QD_TILE_ABLATE == 1
-        if (inside) { redo_flags[pix_index] = 0; zraw[((size_t)e * (N - 1) + ch) * P + p] = emin; }   // diagnostic: search only
-        return;
-#endif
-        const bool ok = qd_tile_ground<N, VALIDATE>(T, Gd, Vv, nS, nSfront, lo_, KM, alive, xs, ys, isa, emin, Ecg * isa, tc, occ, lam, resid, stats);
-        if (stats && lane == 0 && !ok) { atomicAdd(&stats[1], 1ull); atomicAdd(&stats[8 + 6], 1ull); }
-        if (!inside) return;
-        const bool give_up = !ok || !alive;
-        redo_flags[pix_index] = give_up ? 1 : 0;
-        if (give_up) return;
-        // sensor constant c0 = 2 b + a (2 (Ns - v''_s) + 1),  b = sum_i A[N][i] (<n_i> - v''_i)   (qd_k_sensor finishes a15)
-        double b = 0.0;
-#pragma unroll
-        for (int i = 0; i < N; ++i) b = fma(A[N * G + i], occ[i] - vpp[i], b);
-        const double vs = vpp[N];
-        const double Ns = rint(vs);
-        const size_t gp = ((size_t)e * (N - 1) + ch) * P + p;
-        zraw[gp] = 2.0 * b + A[N * G + N] * (2.0 * (Ns - vs) + 1.0);
-        if (occ_out) {
-#pragma unroll
-            for (int i = 0; i < N; ++i) occ_out[gp * N + i] = occ[i];
-        }
-        if constexpr (VALIDATE) {
-            if (eig_out) { eig_out[gp * 2] = lam + Ecg * isa; eig_out[gp * 2 + 1] = resid; }
-        }
     }
 }
 

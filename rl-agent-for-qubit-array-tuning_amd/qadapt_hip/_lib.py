@@ -12,7 +12,6 @@ LIB_PATH = os.environ.get("QDSIM_LIB", os.path.join(CSRC, "libqdsim.so"))   # QD
 
 QD_FLAG_VALIDATE = 1
 QD_FLAG_PIXEL_SEARCH = 2
-QD_FLAG_TILE_FUSED = 4
 QD_NOISE_SENSOR = 1
 QD_NOISE_RADIAL = 2
 QD_NOISE_LATCH = 4
@@ -21,7 +20,7 @@ EXPORTS = [
     "qd_param_block_doubles", "qd_state_block_doubles", "qd_layout_query", "qd_create", "qd_destroy",
     "qd_last_error", "qd_bind_outputs", "qd_load_episodes", "qd_apply_actions", "qd_observe",
     "qd_update_capacitance", "qd_step", "qd_get_state", "qd_set_state", "qd_get_raw",
-    "qd_get_occupations", "qd_get_candidates", "qd_get_eigen", "qd_get_search_stats", "qd_get_rng_state", "qd_set_rng_state",
+    "qd_get_occupations", "qd_get_candidates", "qd_get_eigen", "qd_get_search_stats", "qd_get_solver_stats", "qd_get_rng_state", "qd_set_rng_state",
     "qd_time_ground_kernel", "qd_time_candidates_kernel", "qd_chunk_envs",
 ]
 
@@ -101,6 +100,7 @@ def lib():
     L.qd_get_candidates.argtypes = [vp, vp]; L.qd_get_candidates.restype = ctypes.c_int
     L.qd_get_eigen.argtypes = [vp, dp]; L.qd_get_eigen.restype = ctypes.c_int
     L.qd_get_search_stats.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]; L.qd_get_search_stats.restype = ctypes.c_int
+    L.qd_get_solver_stats.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]; L.qd_get_solver_stats.restype = ctypes.c_int
     L.qd_get_rng_state.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]; L.qd_get_rng_state.restype = ctypes.c_int
     L.qd_set_rng_state.argtypes = [vp, ctypes.c_uint64]; L.qd_set_rng_state.restype = ctypes.c_int
     L.qd_time_ground_kernel.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_float), vp]

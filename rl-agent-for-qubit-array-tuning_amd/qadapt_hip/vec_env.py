@@ -47,10 +47,8 @@ class VecQuantumDeviceEnv:
     def __init__(self, num_envs, num_dots=None, config_path=None, qarray_config_path=None,
                  resolution=None, device=None, seed=None, env_id_offset=0, capacitance_model=None,
                  validate=False, env_chunk=0, reset_kalman_on_reset=False, noise=None,
-                 vary_peak_width=False, peak_width_alpha=0.01, voltage_capacitance_model=None, pixel_search=False,
-                 fused=False):
+                 vary_peak_width=False, peak_width_alpha=0.01, voltage_capacitance_model=None, pixel_search=False):
         """pixel_search: a9 by the per-pixel search only (A/B switch; the default runs one search per 8x8 tile).
-        fused: experimental fused tile kernel (search + ground state, one pixel per lane; QD_FLAG_TILE_FUSED).
         seed: base seed of the per-env device streams (PCG64(seed + global env id)) and the Philox key of
         the stochastic stages; None draws fresh OS entropy, as the reference's unseeded generators do
         (qarray_base_class.py:773-774, env.py:161).
@@ -116,8 +114,8 @@ class VecQuantumDeviceEnv:
         cm = self.config["capacitance_model"]
         cfg = _lib.QdConfig(struct_size=ctypes.sizeof(_lib.QdConfig), n_dot=N, resolution=R, batch=B,
                             max_steps=self.max_steps, env_chunk=int(env_chunk),
-                            flags=(_lib.QD_FLAG_VALIDATE if validate else 0) | (_lib.QD_FLAG_PIXEL_SEARCH if pixel_search else 0)
-                            | (_lib.QD_FLAG_TILE_FUSED if fused else 0), noise_flags=self._noise_flags(noise),
+                            flags=(_lib.QD_FLAG_VALIDATE if validate else 0) | (_lib.QD_FLAG_PIXEL_SEARCH if pixel_search else 0),
+                            noise_flags=self._noise_flags(noise),
                             gate_ramp_start=float(rew["gate_ramp_start"]),
                             gate_quadratic_start=float(rew["gate_quadratic_start"]),
                             barrier_ramp_start=float(rew["barrier_ramp_start"]),
@@ -394,10 +392,18 @@ class VecQuantumDeviceEnv:
         t = max(int(out[0]), 1)
         return {"tiles": int(out[0]), "tiles_redone": int(out[1]), "pixels_redone": int(out[2]),
                 "pixels_redone_few_states": int(out[4]), "mean_superset": int(out[3]) / t,
-                "structures_per_tile": int(out[5]) / t, "multi_state_structures_per_tile": int(out[6]) / t,
-                "solves_per_tile": int(out[7]) / t,
                 "tiles_redone_by_reason": {k: int(out[8 + i]) for i, k in
                                            enumerate(("", "ranges", "seeds", "frontier", "leaves", "superset")) if k}}
+
+    def solver_stats(self):
+        """Eigen-solver counters of the ground-state kernel (validate mode): tasks = hop components of >= 2 states
+        solved, Laguerre iterations per task and per 64-task wave tile (a tile waits for its slowest lane), tasks by size."""
+        out = (ctypes.c_uint64 * 16)()
+        _lib.check(self._h, self._lib.qd_get_solver_stats(self._h, out), "qd_get_solver_stats")
+        tasks, tiles = max(int(out[0]), 1), max(int(out[2]), 1)
+        return {"tasks": int(out[0]), "laguerre_per_task": int(out[1]) / tasks, "tiles": int(out[2]),
+                "laguerre_per_tile_max": int(out[3]) / tiles, "lane_fill": int(out[0]) / (64.0 * tiles),
+                "tasks_by_size": {("9+" if k == 7 else str(k + 2)): int(out[4 + k]) for k in range(8)}}
 
     def candidates(self):
         st = np.zeros((self.B, self.C, self.R * self.R, 32, self.N), np.int32)

@@ -10,10 +10,10 @@ import helpers as H
 ap = argparse.ArgumentParser()
 ap.add_argument("--dots", type=int, default=8); ap.add_argument("--envs", type=int, default=128)
 ap.add_argument("--resolution", type=int, default=64); ap.add_argument("--modes", default="start,near,mid")
-ap.add_argument("--iters", type=int, default=3); ap.add_argument("--pixel-search", action="store_true"); ap.add_argument("--fused", action="store_true")
+ap.add_argument("--iters", type=int, default=3); ap.add_argument("--pixel-search", action="store_true")
 a = ap.parse_args()
 env = VecQuantumDeviceEnv(a.envs, num_dots=a.dots, resolution=a.resolution, seed=1234, capacitance_model=SyntheticCapacitanceModel(1),
-                          pixel_search=a.pixel_search, fused=a.fused)
+                          pixel_search=a.pixel_search)
 env.reset()
 st0, steps = env.get_state()
 rng = np.random.default_rng(0)

@@ -1,12 +1,15 @@
 // qd_hosttest.cpp -- CPU-only TEST HARNESS around the __host__ __device__ code
-// in qd_pixel.h.  It exists so the per-pixel device code (sweep, continuous
-// state, exact k-best search, sensor stage) can be checked against the oracle
-// in the no-GPU test tier.  It is NOT part of the product: nothing in
-// qadapt_hip loads it, and it contains no ground-state solver (that stage only
-// exists as HIP code).  Built by tests/hosttest/Makefile.
+// in qd_pixel.h and qd_eig.h.  It exists so the per-pixel device code (sweep,
+// continuous state, exact k-best search, sensor stage) and the per-task dense
+// eigen-solver of the ground-state kernel can be checked against the oracle /
+// numpy in the no-GPU test tier.  It is NOT part of the product: nothing in
+// qadapt_hip loads it (the hop structure / task emission / selection phases of the
+// ground-state kernel only exist as HIP code).  Built by tests/hosttest/Makefile.
 #include <string.h>
 #include "qd_pixel.h"
 #include "qd_rng.h"
+#include "qd_eig.h"
+#include <stdlib.h>
 
 template <int N>
 static int run_front(const double* par, const double* st, int ch, int R, int p0, int p1,
@@ -75,4 +78,23 @@ extern "C" void qdh_normals(uint32_t k0, uint32_t k1, int n, double* out) {
         double a, b; qd_normal2(r, a, b);
         out[i] = a; if (i + 1 < n) out[i + 1] = b;
     }
+}
+
+// lowest eigenpair of one packed symmetric block with the kernel's own solver (csrc/qd_eig.h): register version for
+// s <= QD_EIG_REG, in-memory version above
+extern "C" int qdh_eig_lowest(int s, const double* packed, double* lam, double* x, double* resid, int* iters) {
+    switch (s) {
+#define C(n) case n: qd_eig_lowest<n, true>(packed, *lam, x, *resid, iters); return 0;
+        C(2) C(3) C(4) C(5) C(6) C(7) C(8)
+#undef C
+    }
+    if (s < 2 || s > 32) return 1;
+    const int ne = s * (s + 1) / 2;
+    double* M = (double*)malloc(sizeof(double) * (ne + 4 * s));
+    if (!M) return 2;
+    memcpy(M, packed, sizeof(double) * ne);
+    qd_eig_lowest_mem(s, M, M + ne, packed, *lam, *resid, iters);
+    memcpy(x, M + ne + 3 * s, sizeof(double) * s);
+    free(M);
+    return 0;
 }
