@@ -10,8 +10,10 @@ The reference steps ONE env per RLlib runner through `MultiAgentEnvWrapper`
   BatchedMultiAgentEnv    B logical envs over one backend.  step(list of B action dicts) packs all actions into
                           one (B, 2N-1) tensor, launches ONCE, copies the kernel-written per-agent tensors
                           (`plunger_images`, `barrier_images`, `voltages`, rewards, flags) to a pinned host mirror
-                          and hands out numpy VIEWS of that mirror, agent by agent.  Nothing is re-derived on the
-                          host.  This is the vector form RLlib's vectorised multi-agent runners call.
+                          and hands out FRESH numpy arrays per step (one bulk copy of the mirror per tensor, then
+                          views per agent), as the reference wrapper does; `zero_copy=True` hands out views of the
+                          2-deep pinned ring itself (valid for ONE further step only).  Nothing is re-derived on
+                          the host.  This is the vector form RLlib's vectorised multi-agent runners call.
   MultiAgentEnvView       env i of a batch with the exact single-env surface of the reference wrapper (reset / step /
                           observation_spaces / action_spaces / get_agent_ids / close).  step() stages the view's
                           actions; the launch happens when the last view of the batch has staged (lazy batched step).
@@ -130,20 +132,26 @@ class AgentRoster:
 
 # ----------------------------------------------------------------------------------------------------------
 class _HostMirror:
-    """Pinned host copies of the tensors a step produces, double buffered: the arrays returned for step t stay
-    untouched while step t+1 is being produced (the reference returns fresh arrays every call)."""
+    """Pinned host copies of the tensors a step produces.  By default every pull() hands out FRESH numpy arrays (one
+    bulk copy out of the pinned staging buffers per tensor), because consumers keep observations: RLlib episode buffers
+    and host-side frame stacking hold the arrays of step t long after step t+2, and the reference wrapper returns new
+    arrays every call (multi_agent_wrapper.py:311-383).  zero_copy=True hands out views of the 2-deep pinned ring
+    instead: the arrays of step t are overwritten by step t+2 -- only for consumers that copy or finish with an
+    observation before stepping twice."""
 
-    def __init__(self, vec, with_global):
+    def __init__(self, vec, with_global, zero_copy=False):
         import torch
         self.torch = torch
         self.vec = vec
+        self.zero_copy = bool(zero_copy)
         names = ["plunger_images", "barrier_images", "voltages", "rewards", "truncated"] + (["global_image"] if with_global else [])
+        self.on_gpu = getattr(vec, "plunger_images").is_cuda         # (host tensors only in the CPU-tier tests)
         self.sets = []
         for _ in range(2):
             s = {}
             for n in names:
                 t = getattr(vec, n)
-                s[n] = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+                s[n] = torch.empty(t.shape, dtype=t.dtype, pin_memory=self.on_gpu)
             self.sets.append(s)
         self.turn = 0
 
@@ -153,8 +161,11 @@ class _HostMirror:
         s = self.sets[self.turn]; self.turn ^= 1
         for n, host in s.items():
             host.copy_(getattr(self.vec, n), non_blocking=True)
-        torch.cuda.current_stream(self.vec.device).synchronize()
-        return {n: h.numpy() for n, h in s.items()}
+        if self.on_gpu:
+            torch.cuda.current_stream(self.vec.device).synchronize()
+        if self.zero_copy:
+            return {n: h.numpy() for n, h in s.items()}
+        return {n: h.numpy().copy() for n, h in s.items()}
 
 
 class BatchedMultiAgentEnv:
@@ -165,7 +176,10 @@ class BatchedMultiAgentEnv:
     CPU-tier tests pass a fake."""
 
     def __init__(self, num_envs=None, return_voltage=True, return_global_state=False, env_config_path=None,
-                 capacitance_model=None, backend=None, auto_reset=False, **vec_kwargs):
+                 capacitance_model=None, backend=None, auto_reset=True, zero_copy=False, **vec_kwargs):
+        """auto_reset (default True): an env that truncates gets a new random device and a fresh first observation inside
+        the same batched step, the way a vectorised runner expects; with False a truncated env stays truncated until
+        its view's reset() (or reset()) is called.  zero_copy: see _HostMirror."""
         if backend is None:
             from .vec_env import VecQuantumDeviceEnv
             backend = VecQuantumDeviceEnv(num_envs, config_path=env_config_path, capacitance_model=capacitance_model,
@@ -177,7 +191,7 @@ class BatchedMultiAgentEnv:
         R = int(backend.R)
         self.roster = AgentRoster(self.num_dots, (R, R), return_voltage, return_global_state)
         self._mirror = backend.make_mirror(return_global_state) if hasattr(backend, "make_mirror") \
-            else _HostMirror(backend, return_global_state)
+            else _HostMirror(backend, return_global_state, zero_copy=zero_copy)
         self._actions = np.zeros((self.B, 2 * self.num_dots - 1), np.float32)
         self._staged = np.zeros(self.B, bool)
         self._results = [None] * self.B
@@ -205,6 +219,24 @@ class BatchedMultiAgentEnv:
             self.reset()
         host, ds = self._latest
         return self._obs_of(host, b), self._reset_info(ds, b)
+
+    def reset_env(self, b, seed=None):
+        """Reset env b ALONE (new random device, step counter 0, fresh first observation), as the reference wrapper's
+        reset() does for its one env (multi_agent_wrapper.py:459-483 -> env.py:135-237)."""
+        if self._latest is None:
+            self.reset(seed=seed)
+            return self.current(b)
+        self.vec.reset(env_ids=[b], seed=seed)
+        host = self._mirror.pull()
+        ds = self.vec.device_state()
+        self._latest = (host, ds)
+        return self._obs_of(host, b), self._reset_info(ds, b)
+
+    def needs_reset(self, b):
+        """True when env b's episode is over and nothing has replaced it yet (only possible without auto_reset)."""
+        steps = getattr(self.vec, "_steps_host", getattr(self.vec, "steps", None))
+        max_steps = getattr(self.vec, "max_steps", None)
+        return steps is not None and max_steps is not None and int(steps[b]) >= int(max_steps)
 
     def step(self, actions_per_env):
         """actions_per_env: sequence of B dicts agent -> action.  ONE backend step.  Returns five lists of length B
@@ -296,8 +328,12 @@ class MultiAgentEnvView(_RllibBase):
 
     def reset(self, *, seed=None, options=None):
         """The envs of a batch are reset together (first call) and, while running, one by one by the backend when
-        they truncate (auto_reset); a view's reset() therefore returns its env's current first observation and
-        never launches anything by itself."""
+        they truncate (auto_reset, the default): then the env's first observation already exists and is returned
+        without touching the device.  An env that truncated WITHOUT being replaced (auto_reset=False), or an explicit
+        seed, gets a real reset of this env alone: new device, step counter 0, fresh observation -- the reference
+        wrapper's reset semantics (multi_agent_wrapper.py:459-483)."""
+        if seed is not None or self.batch.needs_reset(self.index):
+            return self.batch.reset_env(self.index, seed=seed)
         return self.batch.current(self.index)
 
     def stage(self, agent_actions):

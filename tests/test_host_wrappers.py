@@ -244,8 +244,12 @@ class FakeVec:
                 return {n: getattr(vec, n).copy() for n in names}
         return M()
 
-    def reset(self, seed=None, **kw):
-        self.steps[:] = 0; self._fill()
+    def reset(self, seed=None, env_ids=None, **kw):
+        if env_ids is None:
+            self.steps[:] = 0
+        else:
+            self.steps[np.asarray(env_ids)] = 0; self.single_resets = getattr(self, "single_resets", []) + [list(env_ids)]
+        self._fill()
 
     def step(self, actions, auto_reset=False):
         self.calls += 1; self.last_actions = np.array(actions, copy=True); self.steps += 1; self._fill()
@@ -264,7 +268,7 @@ def test_batched_multi_agent_env_one_launch_per_step():
     from qadapt_hip.multi_agent import BatchedMultiAgentEnv, StepPending
     B, N, R = 5, 4, 6
     vec = FakeVec(B, N, R)
-    env = BatchedMultiAgentEnv(backend=vec, return_voltage=True, return_global_state=True)
+    env = BatchedMultiAgentEnv(backend=vec, return_voltage=True, return_global_state=True, auto_reset=False)
     ids = env.roster.ids
     obs, infos = env.reset()
     assert len(obs) == B and set(obs[0]) == set(ids) and "current_device_state" in infos[2]["barrier_1"]
@@ -304,3 +308,70 @@ def test_batched_multi_agent_env_one_launch_per_step():
     assert vec.calls == 4 and np.array_equal(o["plunger_0"]["image"], vec.plunger_images[2, 0])
     with pytest.raises(ValueError):
         env.step(acts[:2])
+
+
+def test_observations_handed_out_stay_valid_for_later_steps():
+    """consumers (RLlib episode buffers, host-side frame stacking) keep observations for many steps.  The
+    default hands out fresh arrays; zero_copy=True documents and shows the 2-deep ring's lifetime."""
+    import torch
+    from qadapt_hip.multi_agent import BatchedMultiAgentEnv, _HostMirror
+
+    class TorchVec(FakeVec):
+        """FakeVec with torch (CPU) output tensors, so that the real _HostMirror runs"""
+        device = torch.device("cpu")
+
+        def _fill(self):
+            FakeVec._fill(self)
+            for n in ("plunger_images", "barrier_images", "global_image", "voltages", "rewards", "truncated"):
+                setattr(self, n, torch.as_tensor(getattr(self, n)))
+
+    B, N, R = 3, 4, 5
+    for zero_copy in (False, True):
+        vec = TorchVec(B, N, R)
+        env = BatchedMultiAgentEnv(backend=vec, return_voltage=True, return_global_state=True, zero_copy=zero_copy)
+        env._mirror = _HostMirror(vec, True, zero_copy=zero_copy)         # the real mirror instead of FakeVec's
+        acts = [{a: np.zeros(1, np.float32) for a in env.roster.ids} for _ in range(B)]
+        env.reset()
+        obs_t, *_ = env.step(acts)
+        kept = obs_t[1]["plunger_2"]["image"]; snapshot = kept.copy()
+        gkept = obs_t[0]["barrier_0"]["global_image"]; gsnap = gkept.copy()
+        changed_at = None
+        for k in range(1, 4):
+            env.step(acts)
+            if changed_at is None and not np.array_equal(kept, snapshot):
+                changed_at = k
+        if zero_copy:
+            assert changed_at == 2                                 # the ring is two deep: step t's arrays are reused by step t+2
+        else:
+            assert changed_at is None and np.array_equal(gkept, gsnap)
+
+
+def test_view_reset_gives_a_fresh_episode_when_nothing_replaced_the_truncated_one():
+    """with auto_reset=False a truncated env used to get its own last observation back from view.reset(); now the
+    view resets its env alone (new device, step counter 0), as the reference wrapper's reset() does."""
+    from qadapt_hip.multi_agent import BatchedMultiAgentEnv
+    B, N, R = 3, 4, 5
+    vec = FakeVec(B, N, R)
+    env = BatchedMultiAgentEnv(backend=vec, return_voltage=True, auto_reset=False)
+    acts = [{a: np.zeros(1, np.float32) for a in env.roster.ids} for _ in range(B)]
+    env.reset()
+    for _ in range(vec.max_steps):
+        _, _, _, trunc, _ = env.step(acts)
+    assert all(t["__all__"] for t in trunc) and env.needs_reset(1)
+    before = vec.plunger_images.copy()
+    o, info = env.views[1].reset()
+    assert vec.single_resets == [[1]] and vec.steps[1] == 0 and vec.steps[0] == vec.max_steps
+    assert not np.array_equal(o["plunger_0"]["image"], before[1, 0])          # a fresh observation, not the final one
+    assert "current_device_state" in info["plunger_0"]
+    o2, _ = env.views[1].reset()                                                # running episode: no further device reset
+    assert vec.single_resets == [[1]]
+    # default: auto_reset=True, a view's reset() after truncation returns the replacement's first observation without a launch
+    vec2 = FakeVec(B, N, R)
+    env2 = BatchedMultiAgentEnv(backend=vec2, return_voltage=True)
+    assert env2.auto_reset
+    env2.reset()
+    for _ in range(vec2.max_steps):
+        env2.step(acts)
+    calls = vec2.calls
+    env2.views[0].reset()
+    assert vec2.calls == calls and not hasattr(vec2, "single_resets")
