@@ -23,8 +23,11 @@ struct qd_handle {
     unsigned long long* tel; int tel_words;
     unsigned long long* tstats;             // tile-search [0..15] and eigen-solver [16..31] counters (validate mode)
     int tile_search;                        // 0: per-pixel search only; 1: tile-shared candidate search + exact redo pass
-    unsigned char* slabs;                   // private scratch of the persistent ground-state blocks (qd_gs_slab_bytes each)
-    int gs_blocks;                          // blocks the ground-state kernel is launched with (= slabs)
+    unsigned char* slabs;                   // scratch of the ground-state kernels: one slab per batch of QD_GS_PPB pixels in flight
+    unsigned* gtiles;                       // [QD_GS_NBIN] tiles per size class of the launch in flight, then the tile lists
+    int gs_chunk;                           // envs per ground-state launch (<= chunk)
+    size_t gs_batches;                      // slabs allocated = gs_chunk * C * batches per image
+    int cus;                                // compute units of the device
     unsigned long long obs_serial;
     char err[512];
 };
@@ -116,20 +119,37 @@ extern "C" int qd_create(const qd_config* cfg, int device, qd_handle** out) {
     h->C = h->N - 1; h->P = h->R * h->R; h->L = qd_layout(h->N);
     *out = h;
     QD_ON_DEVICE(h);
+    const bool val = (cfg->flags & QD_FLAG_VALIDATE) != 0;
     const size_t per_env_rec = (size_t)h->C * h->P * sizeof(QdPixelRec);
-    int chunk = cfg->env_chunk;
-    if (cfg->flags & QD_FLAG_VALIDATE) chunk = h->B;
-    else if (chunk <= 0) {
-        // candidate records in flight: sized for 288 GB of HBM -- 16 GiB (1 216 envs of the 8-dot 64x64 headline per launch;
-        // measured 8-dot, 1 024 envs: 76 envs per launch 6 240 env-steps/s, 304: 6 500, 1 024: 6 590 -- fewer, fuller launches),
-        // but never more than an eighth of what is free on the device right now
-        size_t budget = (size_t)16 << 30, free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b / 8 < budget) budget = free_b / 8;
-        chunk = (int)(budget / per_env_rec);
-        if (chunk < 1) chunk = 1;
+    const size_t batches_per_env = (size_t)h->C * ((h->P + QD_GS_PPB - 1) / QD_GS_PPB);
+    const size_t per_env_slab = batches_per_env * (qd_gs_slab_bytes(val) + 4 * (qd_gs_tile_off(QD_GS_NBIN, 1)));
+    // scratch in flight per launch, sized for 288 GB of HBM: candidate records (488 B / pixel) + the ground-state slabs
+    // (worst case 5.7 KB / pixel: a pixel whose 32 states form ONE hop component needs a 528-double block) -- 40 GiB, i.e.
+    // 224 envs of the 8-dot 64x64 headline per launch, but never more than a quarter of what is free on the device right now
+    size_t budget = (size_t)40 << 30, free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b / 4 < budget) budget = free_b / 4;
+    int chunk = cfg->env_chunk, gs_chunk;
+    if (val) {
+        // validate mode keeps every env's records (qd_get_candidates); only the slabs are chunked
+        chunk = h->B;
+        size_t g = budget / per_env_slab;
+        gs_chunk = (int)(g < 1 ? 1 : (g > (size_t)h->B ? (size_t)h->B : g));
+        if (cfg->env_chunk > 0 && cfg->env_chunk < gs_chunk) gs_chunk = cfg->env_chunk;
+    } else {
+        if (chunk <= 0) {
+            size_t g = budget / (per_env_rec + per_env_slab);
+            chunk = (int)(g < 1 ? 1 : g);
+        }
+        if (chunk > h->B) chunk = h->B;
+        gs_chunk = chunk;
     }
-    if (chunk > h->B) chunk = h->B;
     h->chunk = chunk; h->recs_envs = (size_t)chunk;
+    h->gs_chunk = gs_chunk; h->gs_batches = (size_t)gs_chunk * batches_per_env;
+    {
+        hipDeviceProp_t prop;
+        QD_HIP(hipGetDeviceProperties(&prop, device));
+        h->cus = prop.multiProcessorCount;
+    }
     QD_HIP(hipMalloc(&h->params, sizeof(double) * (size_t)h->B * h->L.size));
     QD_HIP(hipMalloc(&h->state, sizeof(double) * (size_t)h->B * h->L.s_size));
     QD_HIP(hipMalloc(&h->steps, sizeof(int) * (size_t)h->B));
@@ -146,21 +166,8 @@ extern "C" int qd_create(const qd_config* cfg, int device, qd_handle** out) {
     // the tile-shared search pays off where neighbouring pixels are close in voltage (fine grids) and needs >= 32
     // candidates valid across a tile (N >= 4); otherwise every pixel is searched on its own
     h->tile_search = (h->N >= 4 && h->R >= 32 && !(cfg->flags & QD_FLAG_PIXEL_SEARCH)) ? 1 : 0;
-    {
-        // persistent ground-state blocks: as many as are resident at once (never more than there are batches), one slab each
-        const bool val = (cfg->flags & QD_FLAG_VALIDATE) != 0;
-        hipDeviceProp_t prop;
-        QD_HIP(hipGetDeviceProperties(&prop, device));
-        int per_cu = 0;
-        if (val) { QD_DISPATCH_N(h->N, QD_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, qd_k_ground<NN, true>, QD_GS_BLOCK, 0))); }
-        else     { QD_DISPATCH_N(h->N, QD_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, qd_k_ground<NN, false>, QD_GS_BLOCK, 0))); }
-        if (per_cu < 1) per_cu = 1;
-        const long batches = (long)chunk * h->C * ((h->P + QD_GS_PPB - 1) / QD_GS_PPB);
-        long blocks = (long)prop.multiProcessorCount * per_cu;
-        if (blocks > batches) blocks = batches;
-        h->gs_blocks = (int)blocks;
-        QD_HIP(hipMalloc(&h->slabs, (size_t)blocks * qd_gs_slab_bytes(val)));
-    }
+    QD_HIP(hipMalloc(&h->slabs, h->gs_batches * qd_gs_slab_bytes(val)));
+    QD_HIP(hipMalloc(&h->gtiles, sizeof(unsigned) * (16 + qd_gs_tile_off(QD_GS_NBIN, h->gs_batches))));
     if (cfg->flags & QD_FLAG_VALIDATE) {
         QD_HIP(hipMalloc(&h->tstats, sizeof(unsigned long long) * 32));
         QD_HIP(hipMemset(h->tstats, 0, sizeof(unsigned long long) * 32));
@@ -192,7 +199,7 @@ extern "C" int qd_create(const qd_config* cfg, int device, qd_handle** out) {
 extern "C" int qd_destroy(qd_handle* h) {
     if (!h) return QD_ERR_ARG;
     QdDeviceGuard guard_(h->device);
-    void* bufs[] = {h->params, h->state, h->steps, h->zraw, h->plohi, h->recs, h->occ, h->tel, h->eig, h->tstats, h->slabs};
+    void* bufs[] = {h->params, h->state, h->steps, h->zraw, h->plohi, h->recs, h->occ, h->tel, h->eig, h->tstats, h->slabs, h->gtiles};
     for (void* b : bufs) if (b) (void)hipFree(b);
     delete h;
     return QD_OK;
@@ -289,17 +296,58 @@ static QdNoiseCfg qd_noise_cfg(const qd_handle* h) {
     return nz;
 }
 
-static int qd_launch_ground(qd_handle* h, const int32_t* env_ids, int base, int cnt, hipStream_t s) {
-    const long batches = (long)cnt * h->C * ((h->P + QD_GS_PPB - 1) / QD_GS_PPB);
-    const int blocks = (int)(batches < h->gs_blocks ? batches : h->gs_blocks);
-    if (h->eig) {
-        QD_DISPATCH_N(h->N, qd_k_ground<NN, true><<<dim3(blocks), dim3(QD_GS_BLOCK), 0, s>>>(env_ids, base, cnt, h->R,
-                                                h->params, h->recs, h->zraw, h->occ, h->state, h->cfg.noise_flags, h->eig, h->slabs, h->tstats));
-    } else {
-        QD_DISPATCH_N(h->N, qd_k_ground<NN, false><<<dim3(blocks), dim3(QD_GS_BLOCK), 0, s>>>(env_ids, base, cnt, h->R,
-                                                h->params, h->recs, h->zraw, h->occ, h->state, h->cfg.noise_flags, nullptr, h->slabs, nullptr));
+template <int BIN>
+static hipError_t qd_launch_solve(qd_handle* h, hipStream_t s) {
+    // persistent waves: as many blocks as are resident at once for this size class's register budget
+    static int per_cu[2] = {0, 0};
+    const int v = h->eig ? 1 : 0;
+    if (!per_cu[v]) {
+        int n = 0;
+        const hipError_t e = v ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, qd_k_gs_solve<BIN, true>, 256, 0)
+                               : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, qd_k_gs_solve<BIN, false>, 256, 0);
+        if (e != hipSuccess) return e;
+        per_cu[v] = n < 1 ? 1 : n;
     }
-    QD_HIP(hipGetLastError());
+    const dim3 grid((unsigned)(h->cus * per_cu[v]));
+    unsigned* tilelist = h->gtiles + 16;
+    if (h->eig) qd_k_gs_solve<BIN, true><<<grid, dim3(256), 0, s>>>(h->slabs, h->gtiles, tilelist, h->gs_batches, h->tstats);
+    else        qd_k_gs_solve<BIN, false><<<grid, dim3(256), 0, s>>>(h->slabs, h->gtiles, tilelist, h->gs_batches, nullptr);
+    return hipGetLastError();
+}
+
+// a11-a13 + a15 for the envs at list positions [base, base + cnt): structure -> solve per size class -> select, in
+// launches of at most gs_chunk envs (the slabs in flight)
+static int qd_launch_ground(qd_handle* h, const int32_t* env_ids, int base, int cnt, hipStream_t s) {
+    const int nb = (h->P + QD_GS_PPB - 1) / QD_GS_PPB;
+    unsigned* tilelist = h->gtiles + 16;
+    // records: product mode keeps one launch chunk (slot = position in the chunk), validate mode all envs (position in the list)
+    const int rec0 = (h->cfg.flags & QD_FLAG_VALIDATE) ? base : 0;
+    for (int off = 0; off < cnt; off += h->gs_chunk) {
+        const int n = cnt - off < h->gs_chunk ? cnt - off : h->gs_chunk;
+        const QdGsGeom g{n, h->C, h->P, nb};
+        const unsigned batches = (unsigned)((size_t)n * h->C * nb);
+        QD_HIP(hipMemsetAsync(h->gtiles, 0, sizeof(unsigned) * 16, s));
+        if (h->eig) {
+            QD_DISPATCH_N(h->N, qd_k_gs_structure<NN, true><<<dim3(batches), dim3(QD_GS_BLOCK), 0, s>>>(env_ids, base + off, rec0 + off, g, h->R,
+                          h->params, h->recs, h->state, h->cfg.noise_flags, h->slabs, h->gtiles, tilelist, h->gs_batches));
+        } else {
+            QD_DISPATCH_N(h->N, qd_k_gs_structure<NN, false><<<dim3(batches), dim3(QD_GS_BLOCK), 0, s>>>(env_ids, base + off, rec0 + off, g, h->R,
+                          h->params, h->recs, h->state, h->cfg.noise_flags, h->slabs, h->gtiles, tilelist, h->gs_batches));
+        }
+        QD_HIP(hipGetLastError());
+        QD_HIP(qd_launch_solve<0>(h, s)); QD_HIP(qd_launch_solve<1>(h, s)); QD_HIP(qd_launch_solve<2>(h, s));
+        QD_HIP(qd_launch_solve<3>(h, s)); QD_HIP(qd_launch_solve<4>(h, s)); QD_HIP(qd_launch_solve<5>(h, s));
+        QD_HIP(qd_launch_solve<6>(h, s)); QD_HIP(qd_launch_solve<7>(h, s)); QD_HIP(qd_launch_solve<8>(h, s));
+        QD_HIP(qd_launch_solve<9>(h, s));
+        if (h->eig) {
+            QD_DISPATCH_N(h->N, qd_k_gs_select<NN, true><<<dim3(batches), dim3(QD_GS_BLOCK), 0, s>>>(env_ids, base + off, rec0 + off, g, h->R,
+                          h->params, h->recs, h->zraw, h->occ, h->state, h->cfg.noise_flags, h->eig, h->slabs));
+        } else {
+            QD_DISPATCH_N(h->N, qd_k_gs_select<NN, false><<<dim3(batches), dim3(QD_GS_BLOCK), 0, s>>>(env_ids, base + off, rec0 + off, g, h->R,
+                          h->params, h->recs, h->zraw, h->occ, h->state, h->cfg.noise_flags, nullptr, h->slabs));
+        }
+        QD_HIP(hipGetLastError());
+    }
     return QD_OK;
 }
 

@@ -12,13 +12,13 @@
 //   4. eigenvector of T from the twisted factorisation of T - lambda (one solve, accurate in every entry)
 //   5. x = Q y, normalised.
 // The same source compiles for the host (tests/hosttest) where it is checked against numpy.linalg.eigh.
-// Sizes 2..QD_EIG_REG run on register arrays with every loop unrolled (template <S>); larger blocks (rare: < 2 % of
-// the tasks) run the same algorithm with run-time loops on the task's record in memory.
+// Sizes 2..QD_EIG_REG run on register arrays with every loop unrolled (template <S>; 9 and 11 padded to 10 and 12); larger
+// blocks (0.1 % of the pixels have one) run the same algorithm with run-time loops on the task's record in memory.
 #pragma once
 #include <math.h>
 #include "qd_common.h"
 
-#define QD_EIG_REG 8           // largest block solved in registers
+#define QD_EIG_REG 12          // largest block solved in registers (sizes 9, 11 padded to 10, 12)
 
 #if defined(__HIP_DEVICE_COMPILE__)
 #define QD_E_ANY(p) (__any((p)) != 0)
@@ -92,18 +92,22 @@ QD_HD bool qd_laguerre_step(double dk, double p1, double d1, double e1, double t
 #define QD_EIG_MAXIT 64
 
 // ---------------------------------------------------------------------------------------------------------------
-// Register version.  Ain: packed lower triangle (S (S+1) / 2 doubles, any memory).  Outputs: lam (same units as Ain),
-// x[S] (unit 2-norm), and with RESID the absolute residual ||A x - lam x||_2.  `iters` (optional) returns the number of
-// Laguerre iterations this lane needed (statistics).
+// Register version.  Ain: packed lower triangle (sz (sz+1) / 2 doubles, any memory), sz <= S.  Outputs: lam (same units as
+// Ain), x[S] (unit 2-norm; zero beyond sz), and with RESID the absolute residual ||A x - lam x||_2.  `iters` (optional)
+// returns the number of Laguerre iterations this lane needed (statistics).
 // ---------------------------------------------------------------------------------------------------------------
 template <int S, bool RESID>
 QD_HD void qd_eig_lowest(const double* Ain, double& lam_out, double* x, double& resid_out,
-                         int* iters = nullptr) {
+                         int* iters = nullptr, int sz = S) {
     constexpr int NE = S * (S + 1) / 2;
 #define QD_IX(i, j) ((i) * ((i) + 1) / 2 + (j))
+    // sz <= S: a smaller block is PADDED to S rows with decoupled states (after the scaling: diagonal 4 > ||A||, zero
+    // couplings), which the reflectors leave alone and whose eigenvalues lie to the right of every real one
     double a[NE];
 #pragma unroll
-    for (int e = 0; e < NE; ++e) a[e] = Ain[e];
+    for (int i = 0; i < S; ++i)
+#pragma unroll
+        for (int j = 0; j <= i; ++j) a[QD_IX(i, j)] = (i < sz) ? Ain[QD_IX(i, j)] : 0.0;
     // ---- 1. scale ----
     double anorm = 0.0;
 #pragma unroll
@@ -117,6 +121,8 @@ QD_HD void qd_eig_lowest(const double* Ain, double& lam_out, double* x, double& 
     qd_pow2_scale(anorm, tsc, tusc);
 #pragma unroll
     for (int e = 0; e < NE; ++e) a[e] *= tsc;
+#pragma unroll
+    for (int i = 0; i < S; ++i) if (i >= sz) a[QD_IX(i, i)] = 4.0;
     // ---- 2. Householder: reflector k zeroes column k below the sub-diagonal; v_k (v_k[k+1] = 1) is kept in the
     // zeroed entries, tau_k beside it.  A block that is tridiagonal already (sigma == 0) is left alone. ----
     double al[S], be[S], tau[S];
@@ -270,8 +276,8 @@ QD_HD void qd_eig_lowest(const double* Ain, double& lam_out, double* x, double& 
         for (int i = 0; i < S; ++i) {
             double acc = -lam_out * y[i];
 #pragma unroll
-            for (int j = 0; j < S; ++j) acc = fma(Ain[j <= i ? QD_IX(i, j) : QD_IX(j, i)], y[j], acc);
-            r2 = fma(acc, acc, r2);
+            for (int j = 0; j < S; ++j) if (i < sz && j < sz) acc = fma(Ain[j <= i ? QD_IX(i, j) : QD_IX(j, i)], y[j], acc);
+            if (i < sz) r2 = fma(acc, acc, r2);
         }
         resid_out = sqrt(r2);
     }

@@ -2,23 +2,25 @@
 // a11-a13; reference: hamiltonian_build.py:12-45, 75-137, 460-483 and ground_state.py:149-162, where a dense 32x32
 // eigh is called per pixel and only column 0 is used).
 //
-// Three phases per batch of QD_GS_PPB pixels, all inside one persistent thread block (qd_k_ground, qd_kernels.h):
+// Three kernels per launch chunk (qd_kernels.h), the image cut into batches of QD_GS_PPB pixels with one slab of
+// scratch per batch:
 //
-//   A  STRUCTURE, one pixel per half-wave, one basis state per lane (qd_ground_structure):
+//   A  STRUCTURE (qd_k_gs_structure), one pixel per half-wave, one basis state per lane (qd_ground_structure):
 //      hop neighbours (states i, j couple over the adjacent pair d iff s_j - s_i = -+e_d +-e_{d+1}; with 4-bit-spaced
 //      delta codes that is a borrow-free nibble difference of 0x1F << 4q or 0xF1 << 4q), coefficients
 //      H_ij = -t_d sqrt(n_from (n_to + 1)) with the occupations of the ROW state (hamiltonian_build.py:125-131),
 //      connected components (hopping conserves the total charge, so H is block diagonal; the padding copies of
 //      |0..0> are always isolated), Gershgorin pruning (a component whose lower bound min(F - sum|H_ij|) exceeds
 //      min F cannot hold the ground state).  Every surviving component of >= 2 states becomes a TASK: its dense
-//      block is written, lower triangle packed, into the block's private slab and its offset appended to the list
-//      of its size class.
-//   B  SOLVE, one TASK per lane (qd_eig.h): Householder tridiagonalisation, Laguerre, inverse iteration; 64 lanes =
-//      64 different blocks of the same size.  (Round 2 ran Lanczos + the serial tridiagonal recurrences with one
-//      state per lane: every member lane of a component repeated the identical computation and a wave paid the
-//      maximum over its ~11 components; plain Lanczos also lost near-degenerate lowest pairs at tc >~ 1e14.)
-//   C  SELECT, one pixel per lane (qd_ground_select): the component with the lowest eigenvalue wins (ties: lowest
-//      candidate index), <n> = sum_m x_m^2 s_m, the sensor constant c0.
+//      block is written, lower triangle packed, into the batch's slab and its offset appended to the list of its
+//      size class; the batch's 64-task tiles are appended to the launch-wide tile list of the class.
+//   B  SOLVE (qd_k_gs_solve<class>, one launch per size class with its own register budget), one TASK per lane
+//      (qd_eig.h): Householder tridiagonalisation, Laguerre, twisted factorisation; 64 lanes = 64 different blocks
+//      of the same size.  (Round 2 ran Lanczos + the serial tridiagonal recurrences with one state per lane: every
+//      member lane of a component repeated the identical computation and a wave paid the maximum over its ~11
+//      components; plain Lanczos also lost near-degenerate lowest pairs at tc >~ 1e14.)
+//   C  SELECT (qd_k_gs_select), one pixel per lane (qd_ground_select): the component with the lowest eigenvalue wins
+//      (ties: lowest candidate index), <n> = sum_m x_m^2 s_m, the sensor constant c0.
 // Solving block by block is at least as accurate as one dense 32x32 eigh (no rounding-level mixing of different charge
 // sectors); exactly-zero couplings do not link states, so tc == 0 gives exact integer occupations.
 #pragma once
@@ -30,7 +32,10 @@
 #define QD_NBMAX 14                 // a state has at most 2*(N-1) hop neighbours
 #define QD_GS_BLOCK 256
 #define QD_GS_PPB 256               // pixels per batch (4 waves x 32 iterations x 2 pixels)
-#define QD_GS_NBIN (QD_EIG_REG)     // size classes: 2 .. QD_EIG_REG states (register solver), then "larger" (memory solver)
+// size classes: 2 .. 8 states exactly, 9-10 (solved as 10), 11-12 (as 12), 13-32 (memory solver)
+#define QD_GS_NBIN 10
+__host__ __device__ inline int qd_gs_bin(int s) { return s <= 8 ? s - 2 : (s <= 10 ? 7 : (s <= 12 ? 8 : 9)); }
+__host__ __device__ inline int qd_gs_bin_min(int bin) { return bin <= 6 ? bin + 2 : (bin == 7 ? 9 : (bin == 8 ? 11 : 13)); }
 #define QD_LINK_NONE 0xFFFFFFFFu    // state whose component cannot hold the ground state (Gershgorin)
 #define QD_LINK_SINGLE 0xFFFFFFFEu  // isolated state that can: T = [F]
 
@@ -49,21 +54,21 @@ struct QdWaveLds {
     short pfl[2][8];                // per half: floor(n_cont)
 };
 struct QdBlockLds {
-    unsigned pool_top;              // bump allocator of the block's slab (doubles)
-    unsigned cnt[QD_GS_NBIN];       // tasks per size class: [s - 2] for s <= QD_EIG_REG, last = larger
+    unsigned pool_top;              // bump allocator of the batch's slab (doubles)
+    unsigned cnt[QD_GS_NBIN];       // tasks per size class
 };
 
-// The block's private scratch in HBM/L2 (one per persistent block, reused batch after batch):
-//   pool   task records: [0] lambda (out), [1] residual (out; in: the size, for the memory solver),
-//          [2 ..] packed lower triangle (in), overwritten by x[0..s-1] (out); larger blocks carry a 4 s workspace
+// One batch's scratch in HBM/L2:
+//   pool   task records: [0] lambda (out), [1] residual (out; in: the size, for the padded / memory solvers),
+//          [2 ..] packed lower triangle (in), overwritten by x[0..s-1] (out); blocks of > 12 states carry a 4 s workspace
 //          (+ a copy of the matrix in validate mode)
 //   link   per pixel and state: record offset of its component, QD_LINK_SINGLE or QD_LINK_NONE;  rank: index inside it
-//   lists  per size class: record offsets
+//   lists  per size class: record offsets;  cnt: their lengths
 //   aux    per pixel: ||H||_inf (validate: scale of the residual)
 struct QdSlab {
-    double* pool; unsigned* link; unsigned char* rank; unsigned* lists; double* aux;
+    double* pool; unsigned* link; unsigned char* rank; unsigned* lists; double* aux; unsigned* cnt;
 };
-__host__ __device__ inline int qd_gs_list_cap(int bin) { return QD_GS_PPB * (32 / (bin + 2 > QD_EIG_REG ? QD_EIG_REG + 1 : bin + 2)); }
+__host__ __device__ inline int qd_gs_list_cap(int bin) { return QD_GS_PPB * (32 / qd_gs_bin_min(bin)); }
 __host__ __device__ inline int qd_gs_list_off(int bin) { int o = 0; for (int b = 0; b < bin; ++b) o += qd_gs_list_cap(b); return o; }
 __host__ __device__ inline int qd_gs_task_doubles(int s, bool validate) {
     const int ne = s * (s + 1) / 2;
@@ -77,6 +82,7 @@ __host__ __device__ inline size_t qd_gs_slab_bytes(bool validate) {
     b += (size_t)qd_gs_list_off(QD_GS_NBIN) * 4;          // lists
     b += (size_t)QD_GS_PPB * 8;                           // aux
     b += (size_t)QD_GS_PPB * 32;                          // rank
+    b += 64;                                              // cnt
     return (b + 255) & ~(size_t)255;
 }
 __host__ __device__ inline QdSlab qd_gs_slab(unsigned char* base, bool validate) {
@@ -85,9 +91,13 @@ __host__ __device__ inline QdSlab qd_gs_slab(unsigned char* base, bool validate)
     s.link = (unsigned*)base; base += (size_t)QD_GS_PPB * 32 * 4;
     s.lists = (unsigned*)base; base += (size_t)qd_gs_list_off(QD_GS_NBIN) * 4;
     s.aux = (double*)base; base += (size_t)QD_GS_PPB * 8;
-    s.rank = base;
+    s.rank = base; base += (size_t)QD_GS_PPB * 32;
+    s.cnt = (unsigned*)base;
     return s;
 }
+// launch-wide tile lists: tile descriptor = batch * 128 + tile index inside the batch's list
+__host__ __device__ inline size_t qd_gs_tile_cap(int bin, size_t batches) { return batches * (size_t)((qd_gs_list_cap(bin) + 63) / 64); }
+__host__ __device__ inline size_t qd_gs_tile_off(int bin, size_t batches) { size_t o = 0; for (int b = 0; b < bin; ++b) o += qd_gs_tile_cap(b, batches); return o; }
 
 __device__ __forceinline__ unsigned qd_half_ballot(bool p) {
     unsigned long long b = __ballot(p);
@@ -254,10 +264,10 @@ __device__ __forceinline__ void qd_ground_structure(const QdPixelRec* __restrict
     unsigned base = 0;
     if (solve && r == 0) {
         base = atomicAdd(&S.pool_top, (unsigned)qd_gs_task_doubles(ssz, VALIDATE));
-        const int bin = (ssz > QD_EIG_REG ? QD_EIG_REG + 1 : ssz) - 2;
+        const int bin = qd_gs_bin(ssz);
         const unsigned pos = atomicAdd(&S.cnt[bin], 1u);
         sl.lists[qd_gs_list_off(bin) + pos] = base;
-        if (ssz > QD_EIG_REG) sl.pool[base + 1] = (double)ssz;
+        if (ssz > 8) sl.pool[base + 1] = (double)ssz;
     }
     base = (unsigned)__shfl((int)base, __builtin_ctz(seg), 32);
     if (live) {
@@ -286,23 +296,21 @@ __device__ __forceinline__ void qd_ground_structure(const QdPixelRec* __restrict
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Phase B: one task per lane.  rec: the task's record in the slab.
+// Phase B: one task per lane.  rec: the task's record in the slab.  Returns the Laguerre iterations (statistics).
 // ---------------------------------------------------------------------------------------------------------------
-template <int S, bool VALIDATE>
-__device__ __attribute__((noinline)) int qd_eig_task(double* rec) {
+template <int S, bool PADDED, bool VALIDATE>
+__device__ __forceinline__ int qd_eig_task(double* rec) {
     double lam, resid, x[S];
     int its = 0;
-    qd_eig_lowest<S, VALIDATE>(rec + 2, lam, x, resid, VALIDATE ? &its : nullptr);
+    const int sz = PADDED ? (int)rec[1] : S;
+    qd_eig_lowest<S, VALIDATE>(rec + 2, lam, x, resid, VALIDATE ? &its : nullptr, sz);
     rec[0] = lam; rec[1] = resid;
 #pragma unroll
-    for (int i = 0; i < S; ++i) rec[2 + i] = x[i];
+    for (int i = 0; i < S; ++i) if (i < sz) rec[2 + i] = x[i];
     return its;
 }
-#if defined(QD_DEBUG_DUMP)
-__device__ int qd_dbg_flag = 0;
-#endif
 template <bool VALIDATE>
-__device__ __attribute__((noinline)) int qd_eig_task_mem(double* rec) {
+__device__ __forceinline__ int qd_eig_task_mem(double* rec) {
     const int s = (int)rec[1];
     const int ne = s * (s + 1) / 2;
     double* M = rec + 2;
@@ -312,16 +320,6 @@ __device__ __attribute__((noinline)) int qd_eig_task_mem(double* rec) {
     double lam, resid;
     int its = 0;
     qd_eig_lowest_mem(s, M, work, copy, lam, resid, VALIDATE ? &its : nullptr);
-#if defined(QD_DEBUG_DUMP)
-    if (VALIDATE && !(resid == resid) && atomicAdd(&qd_dbg_flag, 1) == 0) {
-        printf("NaN task s=%d lam=%.17g its=%d lane=%d\n", s, lam, its, (int)(threadIdx.x & 63));
-        for (int i = 0; i < s; ++i) { printf(" row %d:", i); for (int j = 0; j <= i; ++j) printf(" %.17g", copy[i * (i + 1) / 2 + j]); printf("\n"); }
-        printf(" al:"); for (int i = 0; i < s; ++i) printf(" %.6e", work[i]);
-        printf("\n be:"); for (int i = 0; i < s; ++i) printf(" %.6e", work[s + i]);
-        printf("\n y:"); for (int i = 0; i < s; ++i) printf(" %.6e", work[3 * s + i]);
-        printf("\n");
-    }
-#endif
     rec[0] = lam; rec[1] = resid;
     for (int i = 0; i < s; ++i) M[i] = work[3 * s + i];
     return its;
@@ -329,52 +327,82 @@ __device__ __attribute__((noinline)) int qd_eig_task_mem(double* rec) {
 
 // ---------------------------------------------------------------------------------------------------------------
 // Phase C: one pixel per lane.  Returns the occupations, the ground energy (absolute) and, with VALIDATE, the
-// relative residual ||H x - lam x||_2 / ||H||_inf of the winning component's eigenpair.
+// relative residual ||H x - lam x||_2 / ||H||_inf of the winning component's eigenpair.  Written as three rounds of
+// INDEPENDENT loads (links and energies; eigenvalues; the winner's vector) -- a lane's chain of 64 dependent loads was
+// what the first version of this phase spent its time on.
 // ---------------------------------------------------------------------------------------------------------------
 template <int N, bool VALIDATE>
 __device__ __forceinline__ void qd_ground_select(const QdPixelRec* __restrict__ rec, int ps, const QdSlab& sl,
                                                  double* occ, double& lam_out, double& resid_out) {
-    const unsigned* link = sl.link + ps * 32;
-    const unsigned char* rank = sl.rank + ps * 32;
+    const unsigned* __restrict__ link = sl.link + ps * 32;
+    const unsigned char* __restrict__ rank = sl.rank + ps * 32;
+    const double* __restrict__ pool = sl.pool;
     const int nvalid = rec->nvalid;
+    unsigned lk[QD_K];
+    double lam[QD_K];
+    {
+        const uint4* l4 = reinterpret_cast<const uint4*>(link);
+#pragma unroll
+        for (int q = 0; q < QD_K / 4; ++q) { const uint4 v = l4[q]; lk[4 * q] = v.x; lk[4 * q + 1] = v.y; lk[4 * q + 2] = v.z; lk[4 * q + 3] = v.w; }
+    }
     double fshift = INFINITY;
-    for (int m = 0; m < QD_K; ++m) fshift = fmin(fshift, rec->E[m]);
+#pragma unroll
+    for (int m = 0; m < QD_K; ++m) { lam[m] = rec->E[m]; fshift = fmin(fshift, lam[m]); }
+#pragma unroll
+    for (int m = 0; m < QD_K; ++m) {
+        const bool task = lk[m] < QD_LINK_SINGLE;
+        const double lt = pool[task ? lk[m] : 0u];         // (always a valid address; the value is used for tasks only)
+        lam[m] = task ? lt : (lk[m] == QD_LINK_SINGLE ? lam[m] - fshift : INFINITY);
+    }
     // the lowest component; tie between components (exactly equal energies): the state with the lowest candidate
     // index wins -- the reference order puts it first -- independent of the buffer order
-    double best = INFINITY; unsigned bestkey = 0xFFFFFFFFu, wl = QD_LINK_NONE; int bm = 0;
-    for (int m = 0; m < QD_K; ++m) {
-        const unsigned lk = link[m];
-        double lam = INFINITY;
-        if (lk == QD_LINK_SINGLE) lam = rec->E[m] - fshift;
-        else if (lk != QD_LINK_NONE) lam = sl.pool[lk];
-        const unsigned key = (m < nvalid) ? (unsigned)rec->idx[m] : 0xFFFFFFFEu;
-        const bool better = (lam < best) | ((lam == best) & (key < bestkey));
-        if (better) { best = lam; bestkey = key; wl = lk; bm = m; }
-    }
+    unsigned idx2[QD_K / 2];
+    {
+        const uint4* i4 = reinterpret_cast<const uint4*>(rec->idx);
 #pragma unroll
-    for (int i = 0; i < N; ++i) occ[i] = 0.0;
+        for (int q = 0; q < QD_K / 8; ++q) { const uint4 v = i4[q]; idx2[4 * q] = v.x; idx2[4 * q + 1] = v.y; idx2[4 * q + 2] = v.z; idx2[4 * q + 3] = v.w; }
+    }
+    double best = INFINITY; unsigned bestkey = 0xFFFFFFFFu, wl = QD_LINK_NONE; int bm = 0;
+#pragma unroll
+    for (int m = 0; m < QD_K; ++m) {
+        const unsigned code = (idx2[m >> 1] >> (16 * (m & 1))) & 0xFFFFu;
+        const unsigned key = (m < nvalid) ? code : 0xFFFFFFFEu;
+        const bool better = (lam[m] < best) | ((lam[m] == best) & (key < bestkey));
+        if (better) { best = lam[m]; bestkey = key; wl = lk[m]; bm = m; }
+    }
+    const bool wtask = wl < QD_LINK_SINGLE;
+    // the winner's vector: one (predicated) load per member state
+    unsigned rk8[QD_K / 4];
+    {
+        const uint4* r4 = reinterpret_cast<const uint4*>(rank);
+#pragma unroll
+        for (int q = 0; q < QD_K / 16; ++q) { const uint4 v = r4[q]; rk8[4 * q] = v.x; rk8[4 * q + 1] = v.y; rk8[4 * q + 2] = v.z; rk8[4 * q + 3] = v.w; }
+    }
+    double xs[QD_K];
+#pragma unroll
+    for (int m = 0; m < QD_K; ++m) {
+        const bool member = wtask ? (lk[m] == wl) : (m == bm);
+        const unsigned rk = (rk8[m >> 2] >> (8 * (m & 3))) & 0xFFu;
+        double x = 0.0;
+        if (member) x = wtask ? pool[wl + 2 + rk] : 1.0;
+        xs[m] = x;
+    }
     int fl[N];
 #pragma unroll
-    for (int i = 0; i < N; ++i) fl[i] = rec->fl[i];
-    for (int m = 0; m < QD_K; ++m) {
-        const bool member = (wl == QD_LINK_SINGLE) ? (m == bm) : (link[m] == wl);
-        if (member) {
-            double x = 1.0;
-            if (wl != QD_LINK_SINGLE) x = sl.pool[wl + 2 + rank[m]];
-            const double p = x * x;
-            if (m < nvalid) {                              // (the padding lanes are |0..0>)
-                const unsigned code = (unsigned)rec->idx[m];
+    for (int i = 0; i < N; ++i) { occ[i] = 0.0; fl[i] = rec->fl[i]; }
 #pragma unroll
-                for (int i = 0; i < N; ++i)
-                    occ[i] = fma(p, (double)(fl[i] + (int)((code >> (2 * (N - 1 - i))) & 3u) - 1), occ[i]);
-            }
-        }
+    for (int m = 0; m < QD_K; ++m) {
+        const unsigned code = (idx2[m >> 1] >> (16 * (m & 1))) & 0xFFFFu;
+        const double p = (m < nvalid) ? xs[m] * xs[m] : 0.0;          // (the padding lanes are |0..0>)
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+            occ[i] = fma(p, (double)(fl[i] + (int)((code >> (2 * (N - 1 - i))) & 3u) - 1), occ[i]);
     }
     lam_out = best + fshift;
     resid_out = 0.0;
     if (VALIDATE) {
         const double hn = sl.aux[ps];
-        if (wl != QD_LINK_SINGLE && wl != QD_LINK_NONE) resid_out = sl.pool[wl + 1] / (hn > 0.0 ? hn : 1.0);
+        if (wtask) resid_out = pool[wl + 1] / (hn > 0.0 ? hn : 1.0);
     }
 }
 

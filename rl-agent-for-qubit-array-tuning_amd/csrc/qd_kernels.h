@@ -2,7 +2,7 @@
 //
 //   qd_k_actions     a2, a3   one thread per env
 //   qd_k_candidates  a5, a8, a9, a10   one pixel per lane, exact k-best search
-//   qd_k_ground      a11-a13, a15      structure per half-wave -> dense tasks per lane -> selection per lane (qd_groundstate.h)
+//   qd_k_gs_*        a11-a13, a15      structure per half-wave -> dense tasks per lane -> selection per lane (qd_groundstate.h)
 //   qd_k_percentile  a17 (exact 0.5 / 99.5 percentiles, radix select)
 //   qd_k_write_obs   a17, a22 normalise + global / per-agent images + voltages
 //   qd_k_update      a19, a20, a21     Kalman, VGM (SVD pseudo-inverse), ground truth
@@ -10,6 +10,7 @@
 // Data layout in HBM (all per handle):
 //   params [B][L.size] f64, state [B][L.s_size] f64, steps [B] i32
 //   recs   [chunk][C][P] QdPixelRec (scratch between candidates and ground kernels)
+//   slabs  [batches of a launch] scratch of the ground-state kernels (qd_gs_slab_bytes each), tile lists per size class
 //   zraw   [B][C][P] f64 raw sensor signal,  plohi [B][2] f64
 #pragma once
 #include "qd_groundstate.h"
@@ -242,118 +243,148 @@ qd_k_candidates(const int* __restrict__ env_ids, int env_base, int R, const doub
 }
 
 // ---------------------------------------------------------------------------
-// a11-a13 + a15: PERSISTENT blocks, each working through batches of QD_GS_PPB pixels of one (env, channel) image in
-// three phases (qd_groundstate.h): A structure (one pixel per half-wave, one state per lane) -> tasks in the block's
-// private slab, B dense lowest eigenpair (one task per lane, size classes), C selection + occupations + sensor constant
-// (one pixel per lane).  grid = min(batches, resident blocks); slabs: one per block (qd_gs_slab_bytes).
-// stats (validate mode, 16 counters at stats[16..]): tasks, sum of Laguerre iterations, wave tiles, sum of the tiles'
-// maxima, then tasks per size class (2..8, larger).
+// a11-a13 + a15 in three kernels (qd_groundstate.h).  The images of a launch chunk are cut into batches of QD_GS_PPB
+// pixels of one (env, channel); batch b owns slab b.
+//   qd_k_gs_structure  grid = batches, 256 threads: hop structure, one pixel per half-wave -> dense tasks in the slab,
+//                      the batch's 64-task tiles appended to the launch-wide tile list of each size class
+//   qd_k_gs_solve<K>   one launch per size class K (own register budget / occupancy), persistent waves striding over
+//                      the class's tile list: one task per lane
+//   qd_k_gs_select     grid = batches, one pixel per lane: lowest component, occupations, sensor constant
+// stats (validate mode, counters at stats[16..]): tasks, sum of Laguerre iterations, wave tiles, sum of the tiles'
+// maxima, then tasks per size class.
 // ---------------------------------------------------------------------------
+struct QdGsGeom { int n_env, C, P, nb; };               // nb = batches per (env, channel) image
+__device__ __forceinline__ void qd_gs_locate(const QdGsGeom& g, int batch, int& slot, int& ch, int& p0) {
+    slot = batch / (g.C * g.nb);
+    const int rem = batch - slot * g.C * g.nb;
+    ch = rem / g.nb; p0 = (rem - ch * g.nb) * QD_GS_PPB;
+}
+
 #ifndef QD_GS_WAVES
-#define QD_GS_WAVES 2            // waves per SIMD the register budget is set for
+#define QD_GS_WAVES 4            // <= 128 VGPRs and 4 x 36 KB of LDS per CU
 #endif
-template <int N, bool VALIDATE = false>
+template <int N, bool VALIDATE>
 __global__ void __launch_bounds__(QD_GS_BLOCK, QD_GS_WAVES)
-qd_k_ground(const int* __restrict__ env_ids, int env_base, int n_env, int R, const double* __restrict__ params,
-            const QdPixelRec* __restrict__ recs, double* __restrict__ zraw, double* __restrict__ occ_out,
-            const double* __restrict__ state, int noise_flags, double* __restrict__ eig_out,
-            unsigned char* __restrict__ slabs, unsigned long long* __restrict__ stats) {
-    constexpr int G = N + 1, C = N - 1;
+qd_k_gs_structure(const int* __restrict__ env_ids, int env_base, int rec_slot0, QdGsGeom g, int R, const double* __restrict__ params,
+                  const QdPixelRec* __restrict__ recs, const double* __restrict__ state, int noise_flags,
+                  unsigned char* __restrict__ slabs, unsigned* __restrict__ gtiles, unsigned* __restrict__ tilelist, size_t batches_cap) {
     const QdLayout L = qd_layout(N);
-    const int P = R * R;
     __shared__ QdWaveLds sW[QD_GS_BLOCK / 64];
     __shared__ QdBlockLds sB;
-    const QdSlab sl = qd_gs_slab(slabs + (size_t)blockIdx.x * qd_gs_slab_bytes(VALIDATE), VALIDATE);
+    const int batch = blockIdx.x;
+    const QdSlab sl = qd_gs_slab(slabs + (size_t)batch * qd_gs_slab_bytes(VALIDATE), VALIDATE);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    QdWaveLds& W = sW[wave];
-    const int nb = (P + QD_GS_PPB - 1) / QD_GS_PPB;
-    const long total = (long)n_env * C * nb;
-    for (long batch = blockIdx.x; batch < total; batch += gridDim.x) {
-        const int slot = (int)(batch / ((long)C * nb));
-        const int rem = (int)(batch - (long)slot * C * nb);
-        const int ch = rem / nb, p0 = (rem - ch * nb) * QD_GS_PPB;
-        const int e = env_ids ? env_ids[env_base + slot] : env_base + slot;
-        const double* par = params + (size_t)e * L.size;
-        const double* st = state + (size_t)e * L.s_size;
-        if (qd_radial_replaced(par, st, L, ch, noise_flags)) continue;   // qd_k_sensor writes pure noise (block-uniform)
-        const QdPixelRec* rbase = recs + ((size_t)slot * C + ch) * P;
-        if (threadIdx.x <= QD_GS_NBIN) { if (threadIdx.x == 0) sB.pool_top = 0; else sB.cnt[threadIdx.x - 1] = 0; }
-        __syncthreads();
-        // ---- A: structure, 2 pixels per wave and iteration ----
-        for (int it = 0; it < QD_GS_PPB / 8; ++it) {
-            const int ps = wave * (QD_GS_PPB / 4) + it * 2 + (lane >> 5);
-            if (p0 + wave * (QD_GS_PPB / 4) + it * 2 >= P) break;                 // uniform for the wave
-            const int p = p0 + ps;
-            // both halves of a wave run in lock step: clamp instead of exiting
-            const int pc = p < P ? p : P - 1;
-            qd_ground_structure<N, VALIDATE>(rbase + pc, p < P, ps, W, sB, sl);
-        }
-        __syncthreads();
-        // ---- B: one task per lane, tiles of 64 tasks of one size class dealt round-robin to the 4 waves ----
-        {
-            int tbase = 0;
-#pragma unroll
-            for (int bin = 0; bin < QD_GS_NBIN; ++bin) {
-                const int nt = (int)sB.cnt[bin];
-                const int ntile = (nt + 63) >> 6;
-                const unsigned* list = sl.lists + qd_gs_list_off(bin);
-                for (int t = 0; t < ntile; ++t) {
-                    if (((tbase + t) & 3) != wave) continue;
-                    const int idx = t * 64 + lane;
-                    int its = 0;
-                    if (idx < nt) {
-                        double* trec = sl.pool + list[idx];
-                        if (bin == 0) its = qd_eig_task<2, VALIDATE>(trec);
-                        if (bin == 1) its = qd_eig_task<3, VALIDATE>(trec);
-                        if (bin == 2) its = qd_eig_task<4, VALIDATE>(trec);
-                        if (bin == 3) its = qd_eig_task<5, VALIDATE>(trec);
-                        if (bin == 4) its = qd_eig_task<6, VALIDATE>(trec);
-                        if (bin == 5) its = qd_eig_task<7, VALIDATE>(trec);
-                        if (bin == 6) its = qd_eig_task<8, VALIDATE>(trec);
-                        if (bin == 7) its = qd_eig_task_mem<VALIDATE>(trec);
-                    }
-                    if (VALIDATE && stats) {
-                        int sum = its, mx = its;
-#pragma unroll
-                        for (int o = 32; o > 0; o >>= 1) { sum += __shfl_xor(sum, o, 64); mx = max(mx, __shfl_xor(mx, o, 64)); }
-                        if (lane == 0) {
-                            const int here = nt - t * 64 < 64 ? nt - t * 64 : 64;
-                            atomicAdd(&stats[16], (unsigned long long)here); atomicAdd(&stats[17], (unsigned long long)sum);
-                            atomicAdd(&stats[18], 1ull); atomicAdd(&stats[19], (unsigned long long)mx);
-                            atomicAdd(&stats[20 + bin], (unsigned long long)here);
-                        }
-                    }
-                }
-                tbase += ntile;
-            }
-        }
-        __syncthreads();
-        // ---- C: one pixel per lane ----
-        {
-            const int ps = threadIdx.x, p = p0 + ps;
-            if (p < P) {
-                const QdPixelRec* rec = rbase + p;
-                double occ[N], lam, resid;
-                qd_ground_select<N, VALIDATE>(rec, ps, sl, occ, lam, resid);
-                const size_t gp = ((size_t)e * C + ch) * P + p;
-                // hand the sensor stage (qd_k_sensor) the pixel's constant c0 = 2 b + a (2 (Ns - v''_s) + 1):
-                // F_{k+1} - F_k = c0 + 2 a (k + eta)   (closed form of the reference's energy differences),
-                // b = sum_i A[N][i] (<n_i> - v''_i)
-                double b = 0.0;
-#pragma unroll
-                for (int i = 0; i < N; ++i) b = fma(par[L.cdd_inv + N * G + i], occ[i] - rec->vpp[i], b);
-                const double vs = rec->vpp[N];
-                const double Ns = rint(vs);                                 // np.round: half to even
-                zraw[gp] = 2.0 * b + par[L.cdd_inv + N * G + N] * (2.0 * (Ns - vs) + 1.0);
-                if (occ_out) {
-#pragma unroll
-                    for (int i = 0; i < N; ++i) occ_out[gp * N + i] = occ[i];
-                }
-                if (VALIDATE && eig_out) { eig_out[gp * 2] = lam; eig_out[gp * 2 + 1] = resid; }
-            }
-        }
-        __syncthreads();                                     // the slab and the counters are reused by the next batch
+    int slot, ch, p0;
+    qd_gs_locate(g, batch, slot, ch, p0);
+    const int e = env_ids ? env_ids[env_base + slot] : env_base + slot;
+    const double* par = params + (size_t)e * L.size;
+    const double* st = state + (size_t)e * L.s_size;
+    if (qd_radial_replaced(par, st, L, ch, noise_flags)) {               // qd_k_sensor writes pure noise: no tasks
+        if (threadIdx.x < QD_GS_NBIN) sl.cnt[threadIdx.x] = 0;
+        return;
     }
+    const QdPixelRec* rbase = recs + ((size_t)(rec_slot0 + slot) * g.C + ch) * g.P;
+    if (threadIdx.x <= QD_GS_NBIN) { if (threadIdx.x == 0) sB.pool_top = 0; else sB.cnt[threadIdx.x - 1] = 0; }
+    __syncthreads();
+    QdWaveLds& W = sW[wave];
+    for (int it = 0; it < QD_GS_PPB / 8; ++it) {
+        const int ps = wave * (QD_GS_PPB / 4) + it * 2 + (lane >> 5);
+        if (p0 + wave * (QD_GS_PPB / 4) + it * 2 >= g.P) break;                 // uniform for the wave
+        const int p = p0 + ps;
+        // both halves of a wave run in lock step: clamp instead of exiting
+        const int pc = p < g.P ? p : g.P - 1;
+        qd_ground_structure<N, VALIDATE>(rbase + pc, p < g.P, ps, W, sB, sl);
+    }
+    __syncthreads();
+    if (threadIdx.x < QD_GS_NBIN) {
+        const int bin = threadIdx.x;
+        const unsigned nt = sB.cnt[bin];
+        sl.cnt[bin] = nt;
+        const unsigned ntile = (nt + 63u) >> 6;
+        if (ntile) {
+            const unsigned start = atomicAdd(&gtiles[bin], ntile);
+            unsigned* tl = tilelist + qd_gs_tile_off(bin, batches_cap) + start;
+            for (unsigned t = 0; t < ntile; ++t) tl[t] = (unsigned)batch * 128u + t;
+        }
+    }
+}
+
+// size class -> solver
+template <int BIN, bool VALIDATE>
+__device__ __forceinline__ int qd_gs_solve_task(double* rec) {
+    if constexpr (BIN <= 6) return qd_eig_task<BIN + 2, false, VALIDATE>(rec);
+    else if constexpr (BIN == 7) return qd_eig_task<10, true, VALIDATE>(rec);
+    else if constexpr (BIN == 8) return qd_eig_task<12, true, VALIDATE>(rec);
+    else return qd_eig_task_mem<VALIDATE>(rec);
+}
+// (register budgets: the unrolled solvers keep the whole packed block live -- 2: 36, 4: 98, 6: 168, 8: 248 VGPRs)
+template <int BIN> struct QdGsSolveWaves { static constexpr int v = BIN <= 1 ? 6 : (BIN == 2 ? 4 : (BIN == 3 ? 3 : (BIN <= 6 ? 2 : (BIN == 9 ? 4 : 1)))); };
+
+template <int BIN, bool VALIDATE>
+__global__ void __launch_bounds__(256, QdGsSolveWaves<BIN>::v)
+qd_k_gs_solve(unsigned char* __restrict__ slabs, const unsigned* __restrict__ gtiles, const unsigned* __restrict__ tilelist,
+              size_t batches_cap, unsigned long long* __restrict__ stats) {
+    const int lane = threadIdx.x & 63;
+    const unsigned ntile = gtiles[BIN];
+    const unsigned* tl = tilelist + qd_gs_tile_off(BIN, batches_cap);
+    const unsigned nwaves = gridDim.x * 4u;
+    for (unsigned gt = blockIdx.x * 4u + (threadIdx.x >> 6); gt < ntile; gt += nwaves) {
+        const unsigned desc = tl[gt];
+        const unsigned batch = desc >> 7, t = desc & 127u;
+        const QdSlab sl = qd_gs_slab(slabs + (size_t)batch * qd_gs_slab_bytes(VALIDATE), VALIDATE);
+        const int nt = (int)sl.cnt[BIN];
+        const int idx = (int)t * 64 + lane;
+        int its = 0;
+        if (idx < nt) its = qd_gs_solve_task<BIN, VALIDATE>(sl.pool + sl.lists[qd_gs_list_off(BIN) + idx]);
+        if (VALIDATE && stats) {
+            int sum = its, mx = its;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { sum += __shfl_xor(sum, o, 64); mx = max(mx, __shfl_xor(mx, o, 64)); }
+            if (lane == 0) {
+                const int here = nt - (int)t * 64 < 64 ? nt - (int)t * 64 : 64;
+                atomicAdd(&stats[16], (unsigned long long)here); atomicAdd(&stats[17], (unsigned long long)sum);
+                atomicAdd(&stats[18], 1ull); atomicAdd(&stats[19], (unsigned long long)mx);
+                atomicAdd(&stats[20 + BIN], (unsigned long long)here);
+            }
+        }
+    }
+}
+
+template <int N, bool VALIDATE>
+__global__ void __launch_bounds__(QD_GS_BLOCK)
+qd_k_gs_select(const int* __restrict__ env_ids, int env_base, int rec_slot0, QdGsGeom g, int R, const double* __restrict__ params,
+               const QdPixelRec* __restrict__ recs, double* __restrict__ zraw, double* __restrict__ occ_out,
+               const double* __restrict__ state, int noise_flags, double* __restrict__ eig_out, unsigned char* __restrict__ slabs) {
+    constexpr int G = N + 1;
+    const QdLayout L = qd_layout(N);
+    const int batch = blockIdx.x;
+    const QdSlab sl = qd_gs_slab(slabs + (size_t)batch * qd_gs_slab_bytes(VALIDATE), VALIDATE);
+    int slot, ch, p0;
+    qd_gs_locate(g, batch, slot, ch, p0);
+    const int e = env_ids ? env_ids[env_base + slot] : env_base + slot;
+    const double* par = params + (size_t)e * L.size;
+    const double* st = state + (size_t)e * L.s_size;
+    if (qd_radial_replaced(par, st, L, ch, noise_flags)) return;
+    const int ps = threadIdx.x, p = p0 + ps;
+    if (p >= g.P) return;
+    const QdPixelRec* rec = recs + ((size_t)(rec_slot0 + slot) * g.C + ch) * g.P + p;
+    double occ[N], lam, resid;
+    qd_ground_select<N, VALIDATE>(rec, ps, sl, occ, lam, resid);
+    const size_t gp = ((size_t)e * g.C + ch) * g.P + p;
+    // hand the sensor stage (qd_k_sensor) the pixel's constant c0 = 2 b + a (2 (Ns - v''_s) + 1):
+    // F_{k+1} - F_k = c0 + 2 a (k + eta)   (closed form of the reference's energy differences),
+    // b = sum_i A[N][i] (<n_i> - v''_i)
+    double b = 0.0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) b = fma(par[L.cdd_inv + N * G + i], occ[i] - rec->vpp[i], b);
+    const double vs = rec->vpp[N];
+    const double Ns = rint(vs);                                 // np.round: half to even
+    zraw[gp] = 2.0 * b + par[L.cdd_inv + N * G + N] * (2.0 * (Ns - vs) + 1.0);
+    if (occ_out) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) occ_out[gp * N + i] = occ[i];
+    }
+    if (VALIDATE && eig_out) { eig_out[gp * 2] = lam; eig_out[gp * 2 + 1] = resid; }
 }
 
 // ---------------------------------------------------------------------------

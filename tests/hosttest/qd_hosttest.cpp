@@ -85,8 +85,11 @@ extern "C" void qdh_normals(uint32_t k0, uint32_t k1, int n, double* out) {
 extern "C" int qdh_eig_lowest(int s, const double* packed, double* lam, double* x, double* resid, int* iters) {
     switch (s) {
 #define C(n) case n: qd_eig_lowest<n, true>(packed, *lam, x, *resid, iters); return 0;
-        C(2) C(3) C(4) C(5) C(6) C(7) C(8)
+        C(2) C(3) C(4) C(5) C(6) C(7) C(8) C(10) C(12)
 #undef C
+        // odd sizes above 8 run padded, exactly as the kernel's size classes do
+        case 9: { double xx[10]; qd_eig_lowest<10, true>(packed, *lam, xx, *resid, iters, 9); memcpy(x, xx, sizeof(double) * 9); return 0; }
+        case 11: { double xx[12]; qd_eig_lowest<12, true>(packed, *lam, xx, *resid, iters, 11); memcpy(x, xx, sizeof(double) * 11); return 0; }
     }
     if (s < 2 || s > 32) return 1;
     const int ne = s * (s + 1) / 2;
