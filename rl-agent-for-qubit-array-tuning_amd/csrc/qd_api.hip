@@ -28,6 +28,8 @@ struct qd_handle {
     int gs_chunk;                           // envs per ground-state launch (<= chunk)
     size_t gs_batches;                      // slabs allocated = gs_chunk * C * batches per image
     int cus;                                // compute units of the device
+    hipStream_t side;                       // the memory solver of the rare 13..32-state blocks is one long latency chain: it runs
+    hipEvent_t ev_fork, ev_join;            // beside the register solvers of the other size classes
     unsigned long long obs_serial;
     char err[512];
 };
@@ -166,6 +168,9 @@ extern "C" int qd_create(const qd_config* cfg, int device, qd_handle** out) {
     // the tile-shared search pays off where neighbouring pixels are close in voltage (fine grids) and needs >= 32
     // candidates valid across a tile (N >= 4); otherwise every pixel is searched on its own
     h->tile_search = (h->N >= 4 && h->R >= 32 && !(cfg->flags & QD_FLAG_PIXEL_SEARCH)) ? 1 : 0;
+    QD_HIP(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+    QD_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+    QD_HIP(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
     QD_HIP(hipMalloc(&h->slabs, h->gs_batches * qd_gs_slab_bytes(val)));
     QD_HIP(hipMalloc(&h->gtiles, sizeof(unsigned) * (16 + qd_gs_tile_off(QD_GS_NBIN, h->gs_batches))));
     if (cfg->flags & QD_FLAG_VALIDATE) {
@@ -201,6 +206,9 @@ extern "C" int qd_destroy(qd_handle* h) {
     QdDeviceGuard guard_(h->device);
     void* bufs[] = {h->params, h->state, h->steps, h->zraw, h->plohi, h->recs, h->occ, h->tel, h->eig, h->tstats, h->slabs, h->gtiles};
     for (void* b : bufs) if (b) (void)hipFree(b);
+    if (h->side) (void)hipStreamDestroy(h->side);
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     delete h;
     return QD_OK;
 }
@@ -297,7 +305,7 @@ static QdNoiseCfg qd_noise_cfg(const qd_handle* h) {
 }
 
 template <int BIN>
-static hipError_t qd_launch_solve(qd_handle* h, hipStream_t s) {
+static hipError_t qd_launch_solve(qd_handle* h, hipStream_t s) {   // s: the stream this size class runs on
     // persistent waves: as many blocks as are resident at once for this size class's register budget
     static int per_cu[2] = {0, 0};
     const int v = h->eig ? 1 : 0;
@@ -335,10 +343,14 @@ static int qd_launch_ground(qd_handle* h, const int32_t* env_ids, int base, int 
                           h->params, h->recs, h->state, h->cfg.noise_flags, h->slabs, h->gtiles, tilelist, h->gs_batches));
         }
         QD_HIP(hipGetLastError());
+        QD_HIP(hipEventRecord(h->ev_fork, s));
+        QD_HIP(hipStreamWaitEvent(h->side, h->ev_fork, 0));
+        QD_HIP(qd_launch_solve<9>(h, h->side));
+        QD_HIP(hipEventRecord(h->ev_join, h->side));
         QD_HIP(qd_launch_solve<0>(h, s)); QD_HIP(qd_launch_solve<1>(h, s)); QD_HIP(qd_launch_solve<2>(h, s));
         QD_HIP(qd_launch_solve<3>(h, s)); QD_HIP(qd_launch_solve<4>(h, s)); QD_HIP(qd_launch_solve<5>(h, s));
         QD_HIP(qd_launch_solve<6>(h, s)); QD_HIP(qd_launch_solve<7>(h, s)); QD_HIP(qd_launch_solve<8>(h, s));
-        QD_HIP(qd_launch_solve<9>(h, s));
+        QD_HIP(hipStreamWaitEvent(s, h->ev_join, 0));
         if (h->eig) {
             QD_DISPATCH_N(h->N, qd_k_gs_select<NN, true><<<dim3(batches), dim3(QD_GS_BLOCK), 0, s>>>(env_ids, base + off, rec0 + off, g, h->R,
                           h->params, h->recs, h->zraw, h->occ, h->state, h->cfg.noise_flags, h->eig, h->slabs));

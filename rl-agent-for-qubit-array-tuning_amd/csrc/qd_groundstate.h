@@ -64,7 +64,7 @@ struct QdBlockLds {
 //          (+ a copy of the matrix in validate mode)
 //   link   per pixel and state: record offset of its component, QD_LINK_SINGLE or QD_LINK_NONE;  rank: index inside it
 //   lists  per size class: record offsets;  cnt: their lengths
-//   aux    per pixel: ||H||_inf (validate: scale of the residual)
+//   aux    validate mode, per pixel: ||H||_inf (scale of the residual), then the lowest free energy (offset of the eigenvalues)
 struct QdSlab {
     double* pool; unsigned* link; unsigned char* rank; unsigned* lists; double* aux; unsigned* cnt;
 };
@@ -80,7 +80,7 @@ __host__ __device__ inline size_t qd_gs_slab_bytes(bool validate) {
     size_t b = qd_gs_pool_doubles(validate) * 8;
     b += (size_t)QD_GS_PPB * 32 * 4;                      // link
     b += (size_t)qd_gs_list_off(QD_GS_NBIN) * 4;          // lists
-    b += (size_t)QD_GS_PPB * 8;                           // aux
+    b += (size_t)QD_GS_PPB * 16;                          // aux
     b += (size_t)QD_GS_PPB * 32;                          // rank
     b += 64;                                              // cnt
     return (b + 255) & ~(size_t)255;
@@ -90,7 +90,7 @@ __host__ __device__ inline QdSlab qd_gs_slab(unsigned char* base, bool validate)
     s.pool = (double*)base; base += qd_gs_pool_doubles(validate) * 8;
     s.link = (unsigned*)base; base += (size_t)QD_GS_PPB * 32 * 4;
     s.lists = (unsigned*)base; base += (size_t)qd_gs_list_off(QD_GS_NBIN) * 4;
-    s.aux = (double*)base; base += (size_t)QD_GS_PPB * 8;
+    s.aux = (double*)base; base += (size_t)QD_GS_PPB * 16;
     s.rank = base; base += (size_t)QD_GS_PPB * 32;
     s.cnt = (unsigned*)base;
     return s;
@@ -275,7 +275,7 @@ __device__ __forceinline__ void qd_ground_structure(const QdPixelRec* __restrict
         sl.rank[ps * 32 + m] = (unsigned char)r;
         if (VALIDATE) {
             const double hn = -qd_half_min(-(fabs(Fabs) + radius));       // ||H||_inf over the 32 states (unshifted)
-            if (m == 0) sl.aux[ps] = hn;
+            if (m == 0) { sl.aux[ps] = hn; sl.aux[QD_GS_PPB + ps] = fshift; }
         }
     }
     {
@@ -345,14 +345,13 @@ __device__ __forceinline__ void qd_ground_select(const QdPixelRec* __restrict__ 
 #pragma unroll
         for (int q = 0; q < QD_K / 4; ++q) { const uint4 v = l4[q]; lk[4 * q] = v.x; lk[4 * q + 1] = v.y; lk[4 * q + 2] = v.z; lk[4 * q + 3] = v.w; }
     }
-    double fshift = INFINITY;
-#pragma unroll
-    for (int m = 0; m < QD_K; ++m) { lam[m] = rec->E[m]; fshift = fmin(fshift, lam[m]); }
+    // eigenvalues are relative to the pixel's lowest free energy; an isolated state that survived the Gershgorin test
+    // is a state of exactly that energy (its bound F - 0 must not exceed min F): lambda = 0
 #pragma unroll
     for (int m = 0; m < QD_K; ++m) {
         const bool task = lk[m] < QD_LINK_SINGLE;
         const double lt = pool[task ? lk[m] : 0u];         // (always a valid address; the value is used for tasks only)
-        lam[m] = task ? lt : (lk[m] == QD_LINK_SINGLE ? lam[m] - fshift : INFINITY);
+        lam[m] = task ? lt : (lk[m] == QD_LINK_SINGLE ? 0.0 : INFINITY);
     }
     // the lowest component; tie between components (exactly equal energies): the state with the lowest candidate
     // index wins -- the reference order puts it first -- independent of the buffer order
@@ -398,10 +397,11 @@ __device__ __forceinline__ void qd_ground_select(const QdPixelRec* __restrict__ 
         for (int i = 0; i < N; ++i)
             occ[i] = fma(p, (double)(fl[i] + (int)((code >> (2 * (N - 1 - i))) & 3u) - 1), occ[i]);
     }
-    lam_out = best + fshift;
+    lam_out = best;
     resid_out = 0.0;
     if (VALIDATE) {
         const double hn = sl.aux[ps];
+        lam_out = best + sl.aux[QD_GS_PPB + ps];
         if (wtask) resid_out = pool[wl + 1] / (hn > 0.0 ? hn : 1.0);
     }
 }
