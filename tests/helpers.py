@@ -155,5 +155,28 @@ def pixel_spectrum(dev, vgm, origin, gate_v, sensor_v, barrier_v, window, ch, R,
     return dict(lam0=w[:, 0], lam1=w[:, 1], hnorm=hn, rel_gap=(w[:, 1] - w[:, 0]) / hn, tcmax=tc.max(axis=1))
 
 
+def image_parity(oe, gpu_img, gpu_raw, tol=2e-6):
+    """Image parity of ONE env's observation against the oracle env `oe`, pixel by pixel, without a fraction rule.
+    gpu_img (R,R,C) float32 normalised image, gpu_raw (C,P) float64 raw sensor signal of the same observation.
+      * every raw pixel the oracle resolves in float64 (rel_gap > GAP_MIN) agrees within 1e-6 relative;
+      * the oracle's raw image, with ONLY its unresolvable pixels replaced by the GPU's values, is normalised the
+        reference's way (shared percentiles) and must equal the GPU image within `tol` in EVERY pixel.
+    Returns (worst image difference, number of unresolvable pixels)."""
+    N, R = oe.N, oe.R
+    oraw = np.asarray(oe.raw_image, float)                                   # (R,R,C)
+    graw = np.asarray(gpu_raw, float).reshape(N - 1, R, R).transpose(1, 2, 0)
+    hybrid = oraw.copy(); unres = 0
+    for ch in range(N - 1):
+        sp = pixel_spectrum(oe.dev, oe.vgm_at_obs, oe.origin, oe.gate_v, oe.sensor_gt, oe.barrier_v, oe.window, ch, R)
+        bad = (sp["rel_gap"] <= GAP_MIN).reshape(R, R)
+        unres += int(bad.sum())
+        d = np.abs(graw[..., ch] - oraw[..., ch]) / np.maximum(np.abs(oraw[..., ch]), 1e-3)
+        assert np.all(d[~bad] <= 1e-6), (ch, float(d[~bad].max()))
+        hybrid[..., ch][bad] = graw[..., ch][bad]
+    worst = float(np.abs(O.normalise_image(hybrid) - gpu_img).max())
+    assert worst <= tol, (worst, unres)
+    return worst, unres
+
+
 GAP_MIN = 1e-9          # relative gap below which the ground vector is not compared pixel by pixel (measured: no pixel of a 344 064-pixel
                         # random-action sweep with rel_gap >= 1e-10 differs by more than 1e-6, profiles/r02_parity_sweep.txt; 1e-7 until late in round 2)

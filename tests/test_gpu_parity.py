@@ -12,9 +12,9 @@ import helpers as H
 
 pytestmark = pytest.mark.gpu
 
-# bound on the on-device relative residual ||H x - lam x||_2 / ||H||_inf of every pixel's eigenpair: a few
-# thousand float64 ulps (three-term Lanczos without re-orthogonalisation + inverse iteration; measured max ~1e-12)
-RESID_MAX = 1e-11
+# bound on the on-device relative residual ||H x - lam x||_2 / ||H||_inf of EVERY pixel's eigenpair, in every regime
+# (dense per-component solve: Householder + Laguerre + twisted factorisation; measured max ~3e-15)
+RESID_MAX = 1e-13
 
 
 def _env(B, N, R, **kw):
@@ -32,21 +32,6 @@ def _cnn(B, C, seed):
     v = rng.normal(0, 0.1, (B, C, 3)).astype(np.float32)
     lv = rng.uniform(-6, -2, (B, C, 3)).astype(np.float32)
     return v, lv, (torch.as_tensor(v).cuda(), torch.as_tensor(lv).cuda())
-
-
-def _image_ok(oe, img, oimg, tol=2e-6):
-    """Image parity of one oracle env's observation: every pixel within `tol`, unless some pixel of that env is
-    unresolvable in float64 (rel_gap <= GAP_MIN) -- then the shared percentiles may move, and only the bulk is
-    required to agree.  Returns (ok, worst, n_unresolvable)."""
-    N, R = oe.N, oe.R
-    unres = 0
-    for ch in range(N - 1):
-        sp = H.pixel_spectrum(oe.dev, oe.vgm_at_obs, oe.origin, oe.gate_v, oe.sensor_gt, oe.barrier_v, oe.window, ch, R)
-        unres += int((sp["rel_gap"] <= H.GAP_MIN).sum())
-    d = np.abs(img - oimg)
-    if unres == 0:
-        return bool(d.max() <= tol), float(d.max()), 0
-    return bool((d <= tol).mean() > 0.98), float(d.max()), unres
 
 
 def _check_channel(tag, dev, sv, ch, R, cand, occ, raw, eig):
@@ -164,8 +149,7 @@ def test_episode_matches_oracle_env(N, R):
         oobs = oe.reset(so, v0[e], l0[e])
         oenvs.append(oe)
         assert np.allclose(obs["obs_gate_voltages"][e].cpu().numpy(), oobs["obs_gate_voltages"], atol=1e-6)
-        ok, worst, unres = _image_ok(oe, obs["image"][e].cpu().numpy(), oobs["image"])
-        assert ok, (e, worst, unres)
+        H.image_parity(oe, obs["image"][e].cpu().numpy(), env.raw()[0][e])
     ds = env.device_state()
     for e, oe in enumerate(oenvs):
         assert np.allclose(ds["kalman_means"][e], oe.kalman.means, rtol=1e-12, atol=1e-15)
@@ -200,8 +184,7 @@ def test_episode_matches_oracle_env(N, R):
             assert np.isclose(ds["sensor_ground_truth"][e], oe.sensor_gt, rtol=1e-8)
             assert np.allclose(obs["obs_gate_voltages"][e].cpu().numpy(), oobs["obs_gate_voltages"], atol=1e-6)
             assert np.allclose(obs["obs_barrier_voltages"][e].cpu().numpy(), oobs["obs_barrier_voltages"], atol=1e-6)
-            ok, worst, unres = _image_ok(oe, obs["image"][e].cpu().numpy(), oobs["image"])
-            assert ok, (step, e, worst, unres)
+            H.image_parity(oe, obs["image"][e].cpu().numpy(), env.raw()[0][e])
     env.close()
 
 
@@ -418,8 +401,9 @@ def test_full_size_properties_8dot_64():
     for e in range(B):
         assert plohi[e, 0] == np.percentile(raw[e], 0.5) and plohi[e, 1] == np.percentile(raw[e], 99.5)
         assert np.array_equal(img[e], O.normalise_image(raw[e].reshape(N - 1, R, R).transpose(1, 2, 0)))
+    # the ground vector lives in ONE hop component (one total-charge sector), so the total is an integer in EVERY pixel
     tot = occ.sum(axis=-1)
-    assert np.mean(np.abs(tot - np.round(tot)) < 1e-6) > 0.995
+    assert np.abs(tot - np.round(tot)).max() < 1e-9
     assert np.all(occ >= cand.min(axis=3) - 1e-9) and np.all(occ <= cand.max(axis=3) + 1e-9)
     assert np.all(cand >= 0)
     pim = env.plunger_images.cpu().numpy(); bim = env.barrier_images.cpu().numpy()
@@ -650,41 +634,4 @@ def test_config2_shape_in_product_mode_against_oracle():
             full = O.normalise_image(z.reshape(N - 1, R, R).transpose(1, 2, 0))
             assert np.abs(full - img[e]).max() <= 2e-6, (e, np.abs(full - img[e]).max())
     print(f"[parity, product mode] config-2 shape: max relative signal error over resolvable pixels {worst:.2e}")
-    env.close()
-
-
-def test_random_action_regime_findings_of_the_round2_sweep_stay_fixed():
-    """Two defects that only the 458 752-pixel sweep of the bench's regime showed (scripts/parity_sweep.py 8 16 4), kept as a
-    test on exactly those envs: 16 8-dot 64x64 envs, seed 1234, four random-action steps.
-      env 8  (tc up to 4e44, a 12-state winning component): the minors of T overflowed between two rescalings -> an
-             eigenvalue off by 0.2 ||H|| and occupations off by 1 in one pixel family (fixed: T is scaled to ||T|| in [1,2));
-      env 13 (tc ~ 1e21): ghost copies of the converged Ritz value cancelled in the inverse iteration -> occupations off
-             by 1e-5 at an eigen residual of 1e-5 (fixed: inverse iteration starts from e_1)."""
-    import torch
-    from qadapt_hip.vec_env import VecQuantumDeviceEnv, SyntheticCapacitanceModel
-    N, B, R = 8, 16, 64
-    env = VecQuantumDeviceEnv(B, num_dots=N, resolution=R, seed=1234, validate=True, capacitance_model=SyntheticCapacitanceModel(99))
-    env.reset()
-    gen = torch.Generator(device="cpu").manual_seed(99)
-    for _ in range(4):
-        env.step((torch.rand((B, 2 * N - 1), generator=gen) * 2 - 1).cuda())
-    st, _ = env.get_state()
-    env.observe()
-    cand = env.candidates(); occ = env.occupations(); eig = env.eigen()
-    for e, occ_tol in ((8, 1e-6), (13, 5e-6)):
-        dev = H.dev_view(N, env._params_host[e]); sv = H.state_view(N, st[e])
-        worst_occ = worst_lam = 0.0; tcmax = 0.0
-        for ch in range(N - 1):
-            ref = OC.csd_channel(dev, sv.vgm, dev.origin, sv.gate_v, sv.sensor_gt, sv.barrier_v, dev.window, ch, R)
-            assert np.array_equal(cand[e, ch], ref["states"]), (e, ch)
-            sp = H.pixel_spectrum(dev, sv.vgm, dev.origin, sv.gate_v, sv.sensor_gt, sv.barrier_v, dev.window, ch, R, states=ref["states"])
-            worst_lam = max(worst_lam, float((np.abs(eig[e, ch, :, 0] - sp["lam0"]) / sp["hnorm"]).max()))
-            ok = sp["rel_gap"] > H.GAP_MIN
-            if ok.any():
-                worst_occ = max(worst_occ, float(np.abs(occ[e, ch] - ref["occ"]).max(axis=1)[ok].max()))
-            tcmax = max(tcmax, float(sp["tcmax"].max()))
-        print(f"[round-2 sweep findings] env {e}: max tc {tcmax:.1e}, max |lam - lam_oracle| / ||H|| {worst_lam:.1e}, "
-              f"max |occ - oracle| over resolvable pixels {worst_occ:.1e}")
-        assert worst_lam <= 1e-10, (e, worst_lam)
-        assert worst_occ <= occ_tol, (e, worst_occ)
     env.close()
