@@ -50,13 +50,6 @@ def b_alg(N, R):
     return 8 * n_par + 4 * (N - 1) * R * R + 4 * (3 * N - 1) * R * R
 
 
-def f_alg(N, R):
-    """literal-reference flops per env-step."""
-    K, G = 32, N + 1
-    per_pixel = 4 ** N * (2 * N * N + 3 * N) + K * (2 * N * N + 3 * N) + 9 * K ** 3 + 22 * G * G
-    return per_pixel * (N - 1) * R * R
-
-
 def kernel_source_hash():
     """Identity of the HIP sources: counter-derived figures under profiles/ are only quoted for the kernels
     they were measured on."""
@@ -149,21 +142,45 @@ def cpu_baseline_and_parity(N, R, seed, seconds_budget=15.0):
 
 # ----------------------------------------------------------------------------------------------
 def launch_ranks(args, argv):
-    """--gpus N without torchrun: start N rank processes from a parent that never touches the GPU."""
+    """--gpus N without torchrun: start N rank processes from a parent that never touches the GPU.  Every rank prints its
+    own rate to stderr (imbalance is visible), host threads are capped per rank so that N device samplers do not
+    oversubscribe the cores, and the children are POLLED: the first one that fails takes its siblings down with it
+    (they would otherwise sit in a barrier until the backend times out) and its exit code is returned."""
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
+    threads = max(1, (os.cpu_count() or args.gpus) // args.gpus)
     procs = []
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(0 if args.share_gpu else r), WORLD_SIZE=str(args.gpus),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+            env.setdefault(k, str(threads))
         # (QD_BENCH_RANK_SCRIPT: the CPU-tier test of this launcher substitutes a recording stub)
         script = os.environ.get("QD_BENCH_RANK_SCRIPT", os.path.abspath(__file__))
         procs.append(subprocess.Popen([sys.executable, script] + argv, env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
     rc = 0
-    for p in procs:
-        rc = max(rc, abs(p.wait()))
+    live = list(procs)
+    while live and rc == 0:
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0:
+                rc = abs(code) or 1
+                print(f"bench.py: rank {procs.index(p)} exited with code {code}; stopping the other ranks", file=sys.stderr)
+                break
+        else:
+            time.sleep(0.05)
+    for p in live:                                   # only after a failure: stop exactly the processes started here
+        p.terminate()
+    for p in live:
+        try:
+            p.wait(timeout=10)
+        except subprocess.TimeoutExpired:
+            p.kill()
     return rc
 
 
@@ -214,6 +231,7 @@ def run_rank(args, rank, world, local):
     from qadapt_hip.vec_env import VecQuantumDeviceEnv, SyntheticCapacitanceModel
     from qadapt_hip.mixed import MixedVecQuantumDeviceEnv
 
+    local = shard.local_device_index(local, torch.cuda.device_count())     # (HIP_VISIBLE_DEVICES may already select one GPU per rank)
     dist = shard.init(args.backend, local) if world > 1 else None
     torch.cuda.set_device(local)
     dev = torch.device(f"cuda:{local}")
@@ -270,24 +288,26 @@ def run_rank(args, rank, world, local):
         dist.barrier()
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
+    # every rank reports its own rate (stderr): a slow rank / an unbalanced shard shows up here, the JSON line carries the max
+    print(f"[bench rank {rank}/{world}] {B} envs on cuda:{local}: {B * args.steps / dt:.1f} env-steps/s ({dt / args.steps * 1e3:.1f} ms per step)",
+          file=sys.stderr, flush=True)
     dt = shard.max_over_ranks(dt, device=dev if args.backend == "nccl" else None)   # identity when not distributed
 
     if rank == 0:
         total_env_steps = B * world * args.steps
         value = total_env_steps / dt
-        # the dominant kernel of the heaviest bucket: HIP events inside the library, on the launch stream
+        # every hot kernel of the heaviest bucket by itself: HIP events inside the library, on the launch stream, one launch
+        # chunk (`chunk` envs) per launch, on the state the timed steps left behind (the random-action regime)
         Nk = max(parts); ek = parts[Nk]
-        gs_ms = ek.time_ground_kernel(iters=2)
-        cand_ms = ek.time_candidates_kernel(iters=2)
+        kms = ek.time_kernels(iters=2)
         chunk = ek.chunk_envs()
-        dom, dom_ms, sec, sec_ms = (f"qd_k_ground<{Nk}>", gs_ms, f"qd_k_candidates<{Nk}>", cand_ms)
-        if cand_ms > gs_ms:
-            dom, dom_ms, sec, sec_ms = sec, sec_ms, dom, dom_ms
+        dom = max(kms, key=kms.get); dom_ms = kms[dom]
         achieved = b_alg(Nk, R) * chunk / (dom_ms * 1e-3) / 1e9
         prof = profile_figures(Nk, R)
-        traffic = None
-        if prof and prof.get("hbm_bytes_per_env_step") is not None:
-            traffic = prof["hbm_bytes_per_env_step"] * chunk
+        pk = ((prof or {}).get("kernels") or {}).get(dom) or {}
+        traffic = pk.get("hbm_bytes_per_env_step")
+        if traffic is not None:
+            traffic = traffic * chunk
         if mixed:
             workload = (f"mixed N in {{2,4,6,8}} ragged batch, {B} envs per GPU ({B // 4} per dot count), {R}x{R} CSD, "
                         "latched-state model on, buckets on separate HIP streams")
@@ -311,23 +331,27 @@ def run_rank(args, rank, world, local):
                                  "(see DESIGN.md 9), this line reports what is measured"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": dom, "kernel_ms": dom_ms, "envs_per_launch": chunk,
+                         "kernel": f"{dom}<{Nk}>", "kernel_ms": dom_ms, "envs_per_launch": chunk,
                          "algorithmic_bytes_per_env_step": b_alg(Nk, R),
-                         "second_kernel": sec, "second_kernel_ms": sec_ms,
+                         "kernels_ms": {f"{k}<{Nk}>" if k != "qd_k_gs_solve" else "qd_k_gs_solve<all size classes>": v for k, v in kms.items()},
                          "traffic_source": (None if traffic is None else
                                             {"file": "profiles/counters.json", "profile": prof.get("profile"),
                                              "git_rev": prof.get("git_rev"), "kernel_src_sha": prof.get("kernel_src_sha")}),
                          "note": "the faithful path is float64 VALU/LDS bound, not HBM bound (SURVEY 7-H1); "
-                                 "the HBM fraction is reported as the contract asks, see DESIGN.md"},
-            # SURVEY 8(d) asks for both rooflines.  F_alg is the LITERAL reference flop count per env-step
-            # (4^N-candidate scan + dense 32x32 eigh per pixel); the kernels do far less work than that, so the
-            # "literal-equivalent" rate may exceed the float64 vector peak -- it measures algorithmic savings, not
-            # pipeline utilisation (measured VALU issue utilisation: measured_issue_utilisation, when profiled on
-            # this kernel source).
-            "valu": {"literal_flops_per_env_step": f_alg(Nk, R),
-                     "literal_equivalent_tflops": (f_alg(Nk, R) * value / world / 1e12) if not mixed else None,
-                     "fp64_vector_peak_tflops": FP64_VECTOR_PEAK_TFLOPS,
-                     "measured_issue_utilisation": (prof or {}).get("valu_issue_utilisation")},
+                                 "the HBM fraction is reported as the contract asks, the VALU figures below say how busy "
+                                 "the pipeline that binds is; see DESIGN.md"},
+            # The roofline that binds: float64 vector issue.  From the rocprofv3 PMC passes under profiles/ (quoted only when
+            # they were taken on THIS kernel source): per hot kernel the vector-ALU issue utilisation (SQ_ACTIVE_INST_VALU x 4
+            # cycles / (duration of the same profiled dispatch x 2.4 GHz x 1024 SIMDs)), the enabled-lane fraction
+            # (SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU)) and the achieved lane-instruction rate against the peak of
+            # 256 CUs x 4 SIMDs x 16 lanes/clk x 2.4 GHz = 39.3e12 lane-instructions/s (= 78.6 TFLOP/s if every one were an FMA).
+            "valu": ({"peak_lane_instr_per_s": FP64_VECTOR_PEAK_TFLOPS / 2 * 1e12, "fp64_vector_peak_tflops": FP64_VECTOR_PEAK_TFLOPS,
+                      "kernels": {k: {f: v.get(f) for f in ("valu_issue_utilisation", "enabled_lane_fraction", "lane_instr_per_s",
+                                                             "frac_of_peak_lane_instr", "insts_valu_per_pixel", "profiled_ms")}
+                                  for k, v in prof["kernels"].items()},
+                      "source": {"file": "profiles/counters.json", "profile": prof.get("profile"), "workload": prof.get("workload")}}
+                     if prof else {"peak_lane_instr_per_s": FP64_VECTOR_PEAK_TFLOPS / 2 * 1e12, "kernels": None,
+                                   "note": "no PMC profile of this kernel source under profiles/ (scripts/collect_profiles.sh)"}),
             "kernel_src_sha": kernel_source_hash(), "git_rev": git_rev(),
         }
         if not args.no_cpu_baseline and world == 1:          # reported at N = 1 only

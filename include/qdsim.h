@@ -178,13 +178,20 @@ int qd_get_solver_stats(qd_handle* h, uint64_t* out16);
 int qd_get_rng_state(const qd_handle* h, uint64_t* obs_serial);
 int qd_set_rng_state(qd_handle* h, uint64_t obs_serial);
 
-/* Timing hook for bench.py: runs `iters` back-to-back launches of the dominant
- * kernel (ground state) on the current data and returns the mean duration in
- * milliseconds measured with HIP events on `stream`. */
+/* Timing hooks for bench.py: `iters` back-to-back launches over ONE launch chunk (qd_chunk_envs envs) on the current
+ * data, mean duration in milliseconds measured with HIP events on `stream`.
+ *   qd_time_candidates_kernel  the whole candidate search (tile search + per-pixel redo pass)
+ *   qd_time_ground_kernel      the whole ground-state stage (structure + the solve launches + select)
+ *   qd_time_kernels            each kernel (group) by itself; out[QD_TIMED_KERNELS] in the order of qd_timed_kernel_name:
+ *                              tile search, per-pixel redo pass, ground-state structure, the solve launches of all size
+ *                              classes together, ground-state select. */
+#define QD_TIMED_KERNELS 5
 int qd_time_ground_kernel(qd_handle* h, int iters, float* mean_ms, void* stream);
+int qd_time_candidates_kernel(qd_handle* h, int iters, float* mean_ms, void* stream);
+int qd_time_kernels(qd_handle* h, int iters, float* mean_ms_out, void* stream);
+const char* qd_timed_kernel_name(int k);
 /* Number of env-steps one launch of the hot kernels covers (scratch chunk). */
 int qd_chunk_envs(const qd_handle* h);
-int qd_time_candidates_kernel(qd_handle* h, int iters, float* mean_ms, void* stream);
 
 #ifdef __cplusplus
 }

@@ -28,6 +28,9 @@ struct qd_handle {
     int gs_chunk;                           // envs per ground-state launch (<= chunk)
     size_t gs_batches;                      // slabs allocated = gs_chunk * C * batches per image
     int cus;                                // compute units of the device
+    double* stage[2]; size_t stage_cap;     // pinned staging ring of qd_load_episodes (doubles per slot), one event per slot:
+    hipEvent_t stage_ev[2]; int stage_turn; //   the call returns without waiting for the stream
+    bool stage_busy[2];
     hipStream_t side;                       // the memory solver of the rare 13..32-state blocks is one long latency chain: it runs
     hipEvent_t ev_fork, ev_join;            // beside the register solvers of the other size classes
     unsigned long long obs_serial;
@@ -206,6 +209,11 @@ extern "C" int qd_destroy(qd_handle* h) {
     QdDeviceGuard guard_(h->device);
     void* bufs[] = {h->params, h->state, h->steps, h->zraw, h->plohi, h->recs, h->occ, h->tel, h->eig, h->tstats, h->slabs, h->gtiles};
     for (void* b : bufs) if (b) (void)hipFree(b);
+    for (int k = 0; k < 2; ++k) {
+        if (h->stage_busy[k]) (void)hipEventSynchronize(h->stage_ev[k]);
+        if (h->stage[k]) (void)hipHostFree(h->stage[k]);
+        if (h->stage_ev[k]) (void)hipEventDestroy(h->stage_ev[k]);
+    }
     if (h->side) (void)hipStreamDestroy(h->side);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
@@ -232,45 +240,61 @@ extern "C" int qd_load_episodes(qd_handle* h, const int32_t* env_ids, int n, con
         if (env_ids[k] < 0 || env_ids[k] >= h->B) return qd_fail(h, QD_ERR_ARG, "qd_load_episodes: env id out of range");
     bool contiguous = true;
     for (int k = 1; k < n && contiguous; ++k) contiguous = env_ids[k] == env_ids[0] + k;
+    // The caller's (pageable) buffers are copied into a pinned staging slot and uploaded from there; an event per slot
+    // says when the stream has consumed it, so the call returns at once instead of draining the stream -- the host goes on
+    // to queue the resets' observation and the next step while the GPU is still busy with the previous one.
+    const size_t prow = (size_t)L.size, srow = (size_t)L.s_size;
+    const size_t need = (size_t)n * (prow + srow);
+    if (need > h->stage_cap) {
+        for (int k = 0; k < 2; ++k) {
+            if (h->stage_busy[k]) { QD_HIP(hipEventSynchronize(h->stage_ev[k])); h->stage_busy[k] = false; }
+            if (h->stage[k]) { QD_HIP(hipHostFree(h->stage[k])); h->stage[k] = nullptr; }
+        }
+        size_t cap = need < (size_t)64 * (prow + srow) ? (size_t)64 * (prow + srow) : need;
+        for (int k = 0; k < 2; ++k) {
+            QD_HIP(hipHostMalloc((void**)&h->stage[k], sizeof(double) * cap, hipHostMallocDefault));
+            if (!h->stage_ev[k]) QD_HIP(hipEventCreateWithFlags(&h->stage_ev[k], hipEventDisableTiming));
+        }
+        h->stage_cap = cap;
+    }
+    const int slot = h->stage_turn; h->stage_turn ^= 1;
+    if (h->stage_busy[slot]) { QD_HIP(hipEventSynchronize(h->stage_ev[slot])); h->stage_busy[slot] = false; }
+    double* sp = h->stage[slot];
+    double* ss = sp + (size_t)n * prow;
+    memcpy(sp, params, sizeof(double) * (size_t)n * prow);
+    memcpy(ss, state, sizeof(double) * (size_t)n * srow);
     // the state rows uploaded are the first `pre` doubles, or the whole row with fresh Kalman priors
-    double* staged = nullptr;
-    const double* src = state; size_t width = pre;
+    size_t width = pre;
     if (reset_kalman) {
-        staged = (double*)malloc(sizeof(double) * (size_t)n * L.s_size);
-        if (!staged) return qd_fail(h, QD_ERR_NOMEM, "malloc");
         double km[QD_MAXN * QD_MAXN], kv[QD_MAXN * QD_MAXN];
         qd_kalman_priors(h->cfg, N, km, kv);
         for (int k = 0; k < n; ++k) {
-            double* row = staged + (size_t)k * L.s_size;
-            memcpy(row, state + (size_t)k * L.s_size, sizeof(double) * L.s_size);
+            double* row = ss + (size_t)k * srow;
             memcpy(row + L.s_kmean, km, sizeof(double) * N * N);
             memcpy(row + L.s_kvar, kv, sizeof(double) * N * N);
         }
-        src = staged; width = (size_t)L.s_kvar + (size_t)N * N;
+        width = (size_t)L.s_kvar + (size_t)N * N;
     }
     hipError_t er = hipSuccess;
     if (contiguous) {
         const int e0 = env_ids[0];
-        er = hipMemcpyAsync(h->params + (size_t)e0 * L.size, params, sizeof(double) * L.size * n, hipMemcpyHostToDevice, s);
+        er = hipMemcpyAsync(h->params + (size_t)e0 * prow, sp, sizeof(double) * prow * n, hipMemcpyHostToDevice, s);
         if (er == hipSuccess)
-            er = hipMemcpy2DAsync(h->state + (size_t)e0 * L.s_size, sizeof(double) * L.s_size, src,
-                                  sizeof(double) * L.s_size, sizeof(double) * width, n, hipMemcpyHostToDevice, s);
+            er = hipMemcpy2DAsync(h->state + (size_t)e0 * srow, sizeof(double) * srow, ss,
+                                  sizeof(double) * srow, sizeof(double) * width, n, hipMemcpyHostToDevice, s);
         if (er == hipSuccess) er = hipMemsetAsync(h->steps + e0, 0, sizeof(int) * n, s);
     } else {
         for (int k = 0; k < n && er == hipSuccess; ++k) {
             const int e = env_ids[k];
-            er = hipMemcpyAsync(h->params + (size_t)e * L.size, params + (size_t)k * L.size,
-                                sizeof(double) * L.size, hipMemcpyHostToDevice, s);
+            er = hipMemcpyAsync(h->params + (size_t)e * prow, sp + (size_t)k * prow, sizeof(double) * prow, hipMemcpyHostToDevice, s);
             if (er == hipSuccess)
-                er = hipMemcpyAsync(h->state + (size_t)e * L.s_size, src + (size_t)k * L.s_size,
-                                    sizeof(double) * width, hipMemcpyHostToDevice, s);
+                er = hipMemcpyAsync(h->state + (size_t)e * srow, ss + (size_t)k * srow, sizeof(double) * width, hipMemcpyHostToDevice, s);
             if (er == hipSuccess) er = hipMemsetAsync(h->steps + e, 0, sizeof(int), s);
         }
     }
-    // pageable host memory: make sure the copies have consumed the caller's buffers
-    if (er == hipSuccess) er = hipStreamSynchronize(s);
-    free(staged);
+    if (er == hipSuccess) er = hipEventRecord(h->stage_ev[slot], s);
     if (er != hipSuccess) return qd_fail(h, QD_ERR_HIP, "qd_load_episodes: copy", er);
+    h->stage_busy[slot] = true;
     return QD_OK;
 }
 
@@ -325,7 +349,7 @@ static hipError_t qd_launch_solve(qd_handle* h, hipStream_t s) {   // s: the str
 
 // a11-a13 + a15 for the envs at list positions [base, base + cnt): structure -> solve per size class -> select, in
 // launches of at most gs_chunk envs (the slabs in flight)
-static int qd_launch_ground(qd_handle* h, const int32_t* env_ids, int base, int cnt, hipStream_t s) {
+static int qd_launch_ground(qd_handle* h, const int32_t* env_ids, int base, int cnt, hipStream_t s, int stages = 7 /*1 structure, 2 solve, 4 select*/) {
     const int nb = (h->P + QD_GS_PPB - 1) / QD_GS_PPB;
     unsigned* tilelist = h->gtiles + 16;
     // records: product mode keeps one launch chunk (slot = position in the chunk), validate mode all envs (position in the list)
@@ -334,6 +358,7 @@ static int qd_launch_ground(qd_handle* h, const int32_t* env_ids, int base, int 
         const int n = cnt - off < h->gs_chunk ? cnt - off : h->gs_chunk;
         const QdGsGeom g{n, h->C, h->P, nb};
         const unsigned batches = (unsigned)((size_t)n * h->C * nb);
+        if (stages & 1) {
         QD_HIP(hipMemsetAsync(h->gtiles, 0, sizeof(unsigned) * 16, s));
         if (h->eig) {
             QD_DISPATCH_N(h->N, qd_k_gs_structure<NN, true><<<dim3(batches), dim3(QD_GS_BLOCK), 0, s>>>(env_ids, base + off, rec0 + off, g, h->R,
@@ -343,6 +368,8 @@ static int qd_launch_ground(qd_handle* h, const int32_t* env_ids, int base, int 
                           h->params, h->recs, h->state, h->cfg.noise_flags, h->slabs, h->gtiles, tilelist, h->gs_batches));
         }
         QD_HIP(hipGetLastError());
+        }
+        if (stages & 2) {
         QD_HIP(hipEventRecord(h->ev_fork, s));
         QD_HIP(hipStreamWaitEvent(h->side, h->ev_fork, 0));
         QD_HIP(qd_launch_solve<9>(h, h->side));
@@ -351,6 +378,8 @@ static int qd_launch_ground(qd_handle* h, const int32_t* env_ids, int base, int 
         QD_HIP(qd_launch_solve<3>(h, s)); QD_HIP(qd_launch_solve<4>(h, s)); QD_HIP(qd_launch_solve<5>(h, s));
         QD_HIP(qd_launch_solve<6>(h, s)); QD_HIP(qd_launch_solve<7>(h, s)); QD_HIP(qd_launch_solve<8>(h, s));
         QD_HIP(hipStreamWaitEvent(s, h->ev_join, 0));
+        }
+        if (stages & 4) {
         if (h->eig) {
             QD_DISPATCH_N(h->N, qd_k_gs_select<NN, true><<<dim3(batches), dim3(QD_GS_BLOCK), 0, s>>>(env_ids, base + off, rec0 + off, g, h->R,
                           h->params, h->recs, h->zraw, h->occ, h->state, h->cfg.noise_flags, h->eig, h->slabs));
@@ -359,6 +388,7 @@ static int qd_launch_ground(qd_handle* h, const int32_t* env_ids, int base, int 
                           h->params, h->recs, h->zraw, h->occ, h->state, h->cfg.noise_flags, nullptr, h->slabs));
         }
         QD_HIP(hipGetLastError());
+        }
     }
     return QD_OK;
 }
@@ -375,21 +405,25 @@ static int qd_launch_ground(qd_handle* h, const int32_t* env_ids, int base, int 
 
 // a5-a13 for `cnt` envs starting at list position `base`.
 //   tile_search 1: tile search + exact redo pass, then qd_k_ground;  0: per-pixel search, then qd_k_ground.
-static int qd_launch_csd(qd_handle* h, const int32_t* env_ids, int base, int cnt, hipStream_t s, int what /*1 search, 2 ground, 3 both*/) {
+static int qd_launch_csd(qd_handle* h, const int32_t* env_ids, int base, int cnt, hipStream_t s, int what /*1 search, 2 ground, 3 both*/,
+                         int parts = 0 /*timing hooks only: 1 tile search alone, 2 redo pass alone; 4/8/16 structure / solve / select alone*/) {
     const size_t shm = (size_t)QD_K * QD_CAND_BLOCK * (sizeof(double) + sizeof(uint16_t));
     const int sorted = (h->cfg.flags & QD_FLAG_VALIDATE) ? 1 : 0;
     dim3 g1(qd_cand_blocks(h->R), h->C, cnt);
     const int tiles = ((h->R + 7) / 8) * ((h->R + 7) / 8);
     dim3 gt(tiles, h->C, cnt);
+    if (parts & 28) return qd_launch_ground(h, env_ids, base, cnt, s, (parts >> 2) & 7);
     if (what & 1) {
-        if (h->tile_search == 1) {
+        if (h->tile_search == 1 && parts != 2) {
             QD_DISPATCH_TILE(h->N, qd_k_tile<NN><<<gt, dim3(64), 0, s>>>(env_ids, base, h->R, h->params, h->state, h->recs,
                              sorted, h->cfg.noise_flags, h->tstats));
             QD_HIP(hipGetLastError());
         }
-        QD_DISPATCH_N(h->N, qd_k_candidates<NN><<<g1, dim3(QD_CAND_BLOCK), shm, s>>>(env_ids, base, h->R, h->params, h->state, h->recs,
-                                                                                      sorted, h->cfg.noise_flags, h->tile_search));
-        QD_HIP(hipGetLastError());
+        if (parts != 1) {
+            QD_DISPATCH_N(h->N, qd_k_candidates<NN><<<g1, dim3(QD_CAND_BLOCK), shm, s>>>(env_ids, base, h->R, h->params, h->state, h->recs,
+                                                                                          sorted, h->cfg.noise_flags, h->tile_search));
+            QD_HIP(hipGetLastError());
+        }
     }
     if (what & 2) return qd_launch_ground(h, env_ids, base, cnt, s);
     return QD_OK;
@@ -588,6 +622,38 @@ extern "C" int qd_time_candidates_kernel(qd_handle* h, int iters, float* mean_ms
     float ms = 0.f;
     QD_HIP(hipEventElapsedTime(&ms, ev.a, ev.b));
     *mean_ms = ms / iters;
+    return QD_OK;
+}
+
+extern "C" const char* qd_timed_kernel_name(int k) {
+    static const char* names[QD_TIMED_KERNELS] = {"qd_k_tile", "qd_k_candidates", "qd_k_gs_structure", "qd_k_gs_solve", "qd_k_gs_select"};
+    return (k >= 0 && k < QD_TIMED_KERNELS) ? names[k] : "";
+}
+
+extern "C" int qd_time_kernels(qd_handle* h, int iters, float* mean_ms_out, void* stream) {
+    if (!h || iters < 1 || !mean_ms_out) return QD_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    QD_ON_DEVICE(h);
+    QdEventPair ev;
+    if (!ev.ok) return qd_fail(h, QD_ERR_HIP, "hipEventCreate");
+    const int cnt = h->chunk < h->B ? h->chunk : h->B;
+    // (the redo pass consumes the tile search's flags and the solvers overwrite their input blocks: the producing kernel is
+    // re-run, untimed, in front of each of their launches)
+    for (int k = 0; k < QD_TIMED_KERNELS; ++k) {
+        float total = 0.f;
+        for (int i = 0; i < iters; ++i) {
+            if (k == 1 && h->tile_search == 1) { int rc = qd_launch_csd(h, nullptr, 0, cnt, s, 1, 1); if (rc) return rc; }
+            if (k == 3) { int rc = qd_launch_csd(h, nullptr, 0, cnt, s, 1, 4); if (rc) return rc; }
+            QD_HIP(hipEventRecord(ev.a, s));
+            if (!(k == 0 && h->tile_search != 1)) { int rc = qd_launch_csd(h, nullptr, 0, cnt, s, 1, 1 << k); if (rc) return rc; }
+            QD_HIP(hipEventRecord(ev.b, s));
+            QD_HIP(hipEventSynchronize(ev.b));
+            float ms = 0.f;
+            QD_HIP(hipEventElapsedTime(&ms, ev.a, ev.b));
+            total += ms;
+        }
+        mean_ms_out[k] = total / iters;
+    }
     return QD_OK;
 }
 

@@ -21,7 +21,7 @@ EXPORTS = [
     "qd_last_error", "qd_bind_outputs", "qd_load_episodes", "qd_apply_actions", "qd_observe",
     "qd_update_capacitance", "qd_step", "qd_get_state", "qd_set_state", "qd_get_raw",
     "qd_get_occupations", "qd_get_candidates", "qd_get_eigen", "qd_get_search_stats", "qd_get_solver_stats", "qd_get_rng_state", "qd_set_rng_state",
-    "qd_time_ground_kernel", "qd_time_candidates_kernel", "qd_chunk_envs",
+    "qd_time_ground_kernel", "qd_time_candidates_kernel", "qd_time_kernels", "qd_timed_kernel_name", "qd_chunk_envs",
 ]
 
 QD_CURVES = {"constant": 0, "polynomial": 1, "exponential": 2, "linear": 3}
@@ -107,6 +107,8 @@ def lib():
     L.qd_time_ground_kernel.restype = ctypes.c_int
     L.qd_time_candidates_kernel.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_float), vp]
     L.qd_time_candidates_kernel.restype = ctypes.c_int
+    L.qd_time_kernels.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_float), vp]; L.qd_time_kernels.restype = ctypes.c_int
+    L.qd_timed_kernel_name.argtypes = [ctypes.c_int]; L.qd_timed_kernel_name.restype = ctypes.c_char_p
     L.qd_chunk_envs.argtypes = [vp]; L.qd_chunk_envs.restype = ctypes.c_int
     _LIB = L
     return L

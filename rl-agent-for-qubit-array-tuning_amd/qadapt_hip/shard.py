@@ -55,17 +55,29 @@ def shard_mixed(counts: dict, rank: int, world: int, resolution: int = 64):
     return out
 
 
-def init(backend: str, local_rank: int = 0):
+def init(backend: str, local_rank: int = 0, timeout_s: float = 180.0):
+    """Rendezvous of the ranks (used for the bench's barriers and the max of the elapsed time only).  The timeout is short
+    on purpose: a rank that died before the rendezvous must not leave the others waiting for the backend's default half hour."""
+    import datetime
     import torch
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29531")
+    to = datetime.timedelta(seconds=timeout_s)
     if backend == "nccl":
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"), timeout=to)
     else:
-        dist.init_process_group(backend)
+        dist.init_process_group(backend, timeout=to)
     return dist
+
+
+def local_device_index(local_rank: int, visible_devices: int) -> int:
+    """GPU a rank uses: its LOCAL_RANK when the process sees all GPUs of the node, device 0 when the launcher has
+    already narrowed the visibility to one GPU per rank (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES)."""
+    if visible_devices <= 0:
+        raise RuntimeError("no GPU visible to this rank")
+    return local_rank if local_rank < visible_devices else local_rank % visible_devices
 
 
 def max_over_ranks(value: float, device=None) -> float:

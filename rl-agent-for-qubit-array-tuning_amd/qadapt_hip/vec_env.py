@@ -244,7 +244,8 @@ class VecQuantumDeviceEnv:
             return self._obs()
         self.load_new_devices(ids, seed=seed)
         all_envs = ids.size == self.B and np.array_equal(ids, np.arange(self.B))
-        ids_dev = None if all_envs else torch.as_tensor(ids, dtype=torch.int32, device=self.device)
+        # (pinned + non_blocking: a pageable upload would make the host wait for everything queued on the stream before it)
+        ids_dev = None if all_envs else torch.from_numpy(np.ascontiguousarray(ids, dtype=np.int32)).pin_memory().to(self.device, non_blocking=True)
         idp = None if all_envs else ctypes.c_void_p(ids_dev.data_ptr())
         _lib.check(self._h, self._lib.qd_observe(self._h, idp, int(ids.size), self._stream()), "qd_observe")
         if cnn_outputs is not None:
@@ -421,6 +422,13 @@ class VecQuantumDeviceEnv:
         _lib.check(self._h, self._lib.qd_time_candidates_kernel(self._h, iters, ctypes.byref(ms), self._stream()),
                    "qd_time_candidates_kernel")
         return float(ms.value)
+
+    def time_kernels(self, iters=3):
+        """HIP-event duration (ms) of one launch over a launch chunk of each hot kernel: dict name -> ms, in pipeline order
+        (qd_k_tile, qd_k_candidates = redo pass, qd_k_gs_structure, qd_k_gs_solve = all size classes, qd_k_gs_select)."""
+        out = (ctypes.c_float * 5)()
+        _lib.check(self._h, self._lib.qd_time_kernels(self._h, int(iters), out, self._stream()), "qd_time_kernels")
+        return {self._lib.qd_timed_kernel_name(k).decode(): float(out[k]) for k in range(5)}
 
     def chunk_envs(self):
         """env-steps covered by one launch of the hot kernels."""

@@ -11,6 +11,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--dots", type=int, default=8); ap.add_argument("--envs", type=int, default=128)
 ap.add_argument("--resolution", type=int, default=64); ap.add_argument("--modes", default="start,near,mid")
 ap.add_argument("--iters", type=int, default=3); ap.add_argument("--pixel-search", action="store_true")
+ap.add_argument("--each", action="store_true", help="also time every hot kernel by itself")
 a = ap.parse_args()
 env = VecQuantumDeviceEnv(a.envs, num_dots=a.dots, resolution=a.resolution, seed=1234, capacitance_model=SyntheticCapacitanceModel(1),
                           pixel_search=a.pixel_search)
@@ -42,4 +43,7 @@ for mode in a.modes.split(","):
     px = a.envs * (a.dots - 1) * a.resolution ** 2
     print(f"{mode:6s} N={a.dots} B={a.envs}: candidates {c:8.3f} ms ({c*1e6/px:6.2f} ns/px)  ground {g:8.3f} ms ({g*1e6/px:6.2f} ns/px)"
           f"  => kernel-only {a.envs/((c+g)*1e-3):9.1f} env-steps/s", flush=True)
+    if a.each:
+        k = env.time_kernels(a.iters)
+        print(f"{mode:6s} per kernel, us per env-step: " + ", ".join(f"{n} {v * 1e3 / min(a.envs, env.chunk_envs()):.2f}" for n, v in k.items()), flush=True)
 env.close()

@@ -10,11 +10,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 STUB = '''
 import json, os, sys
-rec = {k: os.environ.get(k) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+rec = {k: os.environ.get(k) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "OMP_NUM_THREADS")}
 rec["argv"] = sys.argv[1:]
 json.dump(rec, open(os.path.join(os.environ["QD_STUB_DIR"], "rank%s.json" % rec["RANK"]), "w"))
 if rec["RANK"] == "0":
     print(json.dumps({"n_gpus": int(rec["WORLD_SIZE"])}))
+if os.environ.get("QD_STUB_HANG") and rec["RANK"] != "1":
+    import time
+    time.sleep(600)                                        # a rank stuck in a barrier its dead sibling never reaches
 sys.exit(3 if rec["RANK"] == "1" and os.environ.get("QD_STUB_FAIL") else 0)
 '''
 
@@ -55,3 +58,37 @@ def test_world_size_mismatch_is_refused(tmp_path):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True,
                        text=True, timeout=120)
     assert r.returncode == 2 and "WORLD_SIZE=4" in r.stderr
+
+
+def test_eight_ranks_mixed_config_and_thread_caps(tmp_path):
+    """the shape the driver runs on a whole node: --gpus 8 (here with the recording stub), --config mixed passed through,
+    host threads capped per rank so that 8 device samplers do not oversubscribe the cores"""
+    env = {k: v for k, v in os.environ.items()}
+    env.pop("OMP_NUM_THREADS", None)
+    stub = tmp_path / "stub.py"; stub.write_text(STUB)
+    env.update(QD_BENCH_RANK_SCRIPT=str(stub), QD_STUB_DIR=str(tmp_path))
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--config", "mixed", "--steps", "2", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    recs = [json.load(open(tmp_path / f"rank{k}.json")) for k in range(8)]
+    assert [x["LOCAL_RANK"] for x in recs] == [str(k) for k in range(8)] and all(x["WORLD_SIZE"] == "8" for x in recs)
+    assert all(x["argv"][:4] == ["--gpus", "8", "--config", "mixed"] for x in recs)
+    want = str(max(1, (os.cpu_count() or 8) // 8))
+    assert all(x["OMP_NUM_THREADS"] == want for x in recs)
+
+
+def test_a_dead_rank_takes_its_siblings_down_promptly(tmp_path):
+    """rank 1 dies, the others would wait in a barrier; the parent polls, stops them and returns the failure"""
+    import time
+    t0 = time.time()
+    r = _run(tmp_path, {"QD_STUB_FAIL": "1", "QD_STUB_HANG": "1"}, "--gpus", "3")
+    assert r.returncode == 3 and "rank 1 exited with code 3" in r.stderr
+    assert time.time() - t0 < 60
+
+
+def test_local_device_index_with_narrowed_visibility():
+    sys.path.insert(0, os.path.join(ROOT, "rl-agent-for-qubit-array-tuning_amd"))
+    from qadapt_hip.shard import local_device_index
+    assert [local_device_index(r, 8) for r in range(8)] == list(range(8))
+    assert [local_device_index(r, 1) for r in range(8)] == [0] * 8              # HIP_VISIBLE_DEVICES = one GPU per rank
