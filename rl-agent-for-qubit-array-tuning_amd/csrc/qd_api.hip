@@ -31,8 +31,9 @@ struct qd_handle {
     double* stage[2]; size_t stage_cap;     // pinned staging ring of qd_load_episodes (doubles per slot), one event per slot:
     hipEvent_t stage_ev[2]; int stage_turn; //   the call returns without waiting for the stream
     bool stage_busy[2];
-    hipStream_t side;                       // the memory solver of the rare 13..32-state blocks is one long latency chain: it runs
-    hipEvent_t ev_fork, ev_join;            // beside the register solvers of the other size classes
+    hipStream_t side, side2;                // the solve launches of the size classes run on three streams: the memory solver of the
+    hipEvent_t ev_fork, ev_join, ev_join2;  // rare 13..32-state blocks is one long latency chain, and the short register-solver
+                                            // launches fill each other's tails
     unsigned long long obs_serial;
     char err[512];
 };
@@ -129,9 +130,11 @@ extern "C" int qd_create(const qd_config* cfg, int device, qd_handle** out) {
     const size_t batches_per_env = (size_t)h->C * ((h->P + QD_GS_PPB - 1) / QD_GS_PPB);
     const size_t per_env_slab = batches_per_env * (qd_gs_slab_bytes(val) + 4 * (qd_gs_tile_off(QD_GS_NBIN, 1)));
     // scratch in flight per launch, sized for 288 GB of HBM: candidate records (488 B / pixel) + the ground-state slabs
-    // (worst case 5.7 KB / pixel: a pixel whose 32 states form ONE hop component needs a 528-double block) -- 40 GiB, i.e.
-    // 224 envs of the 8-dot 64x64 headline per launch, but never more than a quarter of what is free on the device right now
-    size_t budget = (size_t)40 << 30, free_b = 0, total_b = 0;
+    // (worst case 5.7 KB / pixel: a pixel whose 32 states form ONE hop component needs a 528-double block) -- 64 GiB, i.e.
+    // 388 envs of the 8-dot 64x64 headline per launch (measured, whole bench: 20 GiB 9 070, 40 GiB 9 670, 64 GiB 9 950 env-steps/s),
+    // but never more than a quarter of what is free on the device right now
+    size_t budget = (size_t)64 << 30, free_b = 0, total_b = 0;
+    if (const char* gib = getenv("QDSIM_SCRATCH_GIB")) { const long g = atol(gib); if (g > 0) budget = (size_t)g << 30; }   // (sizing experiments)
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b / 4 < budget) budget = free_b / 4;
     int chunk = cfg->env_chunk, gs_chunk;
     if (val) {
@@ -147,6 +150,12 @@ extern "C" int qd_create(const qd_config* cfg, int device, qd_handle** out) {
         }
         if (chunk > h->B) chunk = h->B;
         gs_chunk = chunk;
+    }
+    // (tile descriptors carry the batch number in 20 bits)
+    if ((size_t)gs_chunk * batches_per_env > ((size_t)1 << 20) - 1) {
+        gs_chunk = (int)((((size_t)1 << 20) - 1) / batches_per_env);
+        if (gs_chunk < 1) return qd_fail(h, QD_ERR_ARG, "resolution too large for the tile descriptors");
+        if (!val && chunk > gs_chunk) chunk = gs_chunk;
     }
     h->chunk = chunk; h->recs_envs = (size_t)chunk;
     h->gs_chunk = gs_chunk; h->gs_batches = (size_t)gs_chunk * batches_per_env;
@@ -172,8 +181,10 @@ extern "C" int qd_create(const qd_config* cfg, int device, qd_handle** out) {
     // candidates valid across a tile (N >= 4); otherwise every pixel is searched on its own
     h->tile_search = (h->N >= 4 && h->R >= 32 && !(cfg->flags & QD_FLAG_PIXEL_SEARCH)) ? 1 : 0;
     QD_HIP(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+    QD_HIP(hipStreamCreateWithFlags(&h->side2, hipStreamNonBlocking));
     QD_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
     QD_HIP(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+    QD_HIP(hipEventCreateWithFlags(&h->ev_join2, hipEventDisableTiming));
     QD_HIP(hipMalloc(&h->slabs, h->gs_batches * qd_gs_slab_bytes(val)));
     QD_HIP(hipMalloc(&h->gtiles, sizeof(unsigned) * (16 + qd_gs_tile_off(QD_GS_NBIN, h->gs_batches))));
     if (cfg->flags & QD_FLAG_VALIDATE) {
@@ -215,8 +226,10 @@ extern "C" int qd_destroy(qd_handle* h) {
         if (h->stage_ev[k]) (void)hipEventDestroy(h->stage_ev[k]);
     }
     if (h->side) (void)hipStreamDestroy(h->side);
+    if (h->side2) (void)hipStreamDestroy(h->side2);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+    if (h->ev_join2) (void)hipEventDestroy(h->ev_join2);
     delete h;
     return QD_OK;
 }
@@ -372,12 +385,16 @@ static int qd_launch_ground(qd_handle* h, const int32_t* env_ids, int base, int 
         if (stages & 2) {
         QD_HIP(hipEventRecord(h->ev_fork, s));
         QD_HIP(hipStreamWaitEvent(h->side, h->ev_fork, 0));
+        QD_HIP(hipStreamWaitEvent(h->side2, h->ev_fork, 0));
         QD_HIP(qd_launch_solve<9>(h, h->side));
         QD_HIP(hipEventRecord(h->ev_join, h->side));
+        QD_HIP(qd_launch_solve<8>(h, h->side2)); QD_HIP(qd_launch_solve<7>(h, h->side2)); QD_HIP(qd_launch_solve<6>(h, h->side2));
+        QD_HIP(qd_launch_solve<5>(h, h->side2)); QD_HIP(qd_launch_solve<4>(h, h->side2));
+        QD_HIP(hipEventRecord(h->ev_join2, h->side2));
         QD_HIP(qd_launch_solve<0>(h, s)); QD_HIP(qd_launch_solve<1>(h, s)); QD_HIP(qd_launch_solve<2>(h, s));
-        QD_HIP(qd_launch_solve<3>(h, s)); QD_HIP(qd_launch_solve<4>(h, s)); QD_HIP(qd_launch_solve<5>(h, s));
-        QD_HIP(qd_launch_solve<6>(h, s)); QD_HIP(qd_launch_solve<7>(h, s)); QD_HIP(qd_launch_solve<8>(h, s));
+        QD_HIP(qd_launch_solve<3>(h, s));
         QD_HIP(hipStreamWaitEvent(s, h->ev_join, 0));
+        QD_HIP(hipStreamWaitEvent(s, h->ev_join2, 0));
         }
         if (stages & 4) {
         if (h->eig) {

@@ -95,7 +95,7 @@ __host__ __device__ inline QdSlab qd_gs_slab(unsigned char* base, bool validate)
     s.cnt = (unsigned*)base;
     return s;
 }
-// launch-wide tile lists: tile descriptor = batch * 128 + tile index inside the batch's list
+// launch-wide tile lists: tile descriptor = batch << 12 | tile index inside the batch's list << 6 | tasks in the tile - 1
 __host__ __device__ inline size_t qd_gs_tile_cap(int bin, size_t batches) { return batches * (size_t)((qd_gs_list_cap(bin) + 63) / 64); }
 __host__ __device__ inline size_t qd_gs_tile_off(int bin, size_t batches) { size_t o = 0; for (int b = 0; b < bin; ++b) o += qd_gs_tile_cap(b, batches); return o; }
 

@@ -303,8 +303,12 @@ qd_k_gs_structure(const int* __restrict__ env_ids, int env_base, int rec_slot0, 
         const unsigned ntile = (nt + 63u) >> 6;
         if (ntile) {
             const unsigned start = atomicAdd(&gtiles[bin], ntile);
+            // tile descriptor: batch (20 bits) | tile index in the batch's list (6) | tasks in the tile - 1 (6)
             unsigned* tl = tilelist + qd_gs_tile_off(bin, batches_cap) + start;
-            for (unsigned t = 0; t < ntile; ++t) tl[t] = (unsigned)batch * 128u + t;
+            for (unsigned t = 0; t < ntile; ++t) {
+                const unsigned here = nt - t * 64u < 64u ? nt - t * 64u : 64u;
+                tl[t] = ((unsigned)batch << 12) | (t << 6) | (here - 1u);
+            }
         }
     }
 }
@@ -328,20 +332,22 @@ qd_k_gs_solve(unsigned char* __restrict__ slabs, const unsigned* __restrict__ gt
     const unsigned ntile = gtiles[BIN];
     const unsigned* tl = tilelist + qd_gs_tile_off(BIN, batches_cap);
     const unsigned nwaves = gridDim.x * 4u;
-    for (unsigned gt = blockIdx.x * 4u + (threadIdx.x >> 6); gt < ntile; gt += nwaves) {
-        const unsigned desc = tl[gt];
-        const unsigned batch = desc >> 7, t = desc & 127u;
+    unsigned gt = blockIdx.x * 4u + (threadIdx.x >> 6);
+    unsigned desc = gt < ntile ? tl[gt] : 0u;
+    for (; gt < ntile; gt += nwaves) {
+        // the next tile's descriptor is fetched while this tile is solved (one dependent load less per tile)
+        const unsigned next = gt + nwaves < ntile ? tl[gt + nwaves] : 0u;
+        const unsigned batch = desc >> 12, t = (desc >> 6) & 63u;
+        const int here = (int)(desc & 63u) + 1;
+        desc = next;
         const QdSlab sl = qd_gs_slab(slabs + (size_t)batch * qd_gs_slab_bytes(VALIDATE), VALIDATE);
-        const int nt = (int)sl.cnt[BIN];
-        const int idx = (int)t * 64 + lane;
         int its = 0;
-        if (idx < nt) its = qd_gs_solve_task<BIN, VALIDATE>(sl.pool + sl.lists[qd_gs_list_off(BIN) + idx]);
+        if (lane < here) its = qd_gs_solve_task<BIN, VALIDATE>(sl.pool + sl.lists[qd_gs_list_off(BIN) + (int)t * 64 + lane]);
         if (VALIDATE && stats) {
             int sum = its, mx = its;
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) { sum += __shfl_xor(sum, o, 64); mx = max(mx, __shfl_xor(mx, o, 64)); }
             if (lane == 0) {
-                const int here = nt - (int)t * 64 < 64 ? nt - (int)t * 64 : 64;
                 atomicAdd(&stats[16], (unsigned long long)here); atomicAdd(&stats[17], (unsigned long long)sum);
                 atomicAdd(&stats[18], 1ull); atomicAdd(&stats[19], (unsigned long long)mx);
                 atomicAdd(&stats[20 + BIN], (unsigned long long)here);

@@ -23,8 +23,18 @@
 
 #if defined(__HIPCC__)
 
-#define QD_T_FCAP 512          // frontier capacity (partial states per level; 2 x 512 x 12 B of LDS; 832 was tried: the tiles it saves fail on the superset size instead)
-#define QD_T_SCAP 255          // superset capacity (state indices are bytes, 255 = none)
+// Capacities, chosen so that the wave's LDS stays within 32 KB (5 waves per CU; measured: 3 waves per CU cost 14 %, 2 cost 50 %):
+// the frontier ping-pong (2 x 832 x 12 B) hides under the per-lane kept sets (20 KB), the superset arrays take 383 x 28 B.
+// Round 2 ran 512 / 255: across a batch of random devices 20-25 % of the tiles overflowed one of the two IN EVERY REGIME
+// (a tile of some devices spans several electrons) and went to the per-pixel search at 2x the cost of a tile; 832 / 383
+// halves that (8-dot 64x64, 242 envs per launch: tile + redo 51.6 -> 49.4 us per env-step in the random-action regime,
+// 55.8 -> 51.5 near the ground truth); 832 / 511 needs 36 KB (4 waves per CU) and is slower again (55.0).
+#ifndef QD_T_FCAP
+#define QD_T_FCAP 832          // frontier capacity (partial states per level)
+#endif
+#ifndef QD_T_SCAP
+#define QD_T_SCAP 383          // superset capacity
+#endif
 #define QD_T_REDO (-1)         // QdPixelRec.nvalid marker: pixel left to the exact per-pixel search
 
 struct QdTileLds {
@@ -38,6 +48,9 @@ struct QdTileLds {
     } u;
     double sD[QD_T_SCAP], sa[QD_T_SCAP], sb[QD_T_SCAP];
     uint32_t scode[QD_T_SCAP];
+#if defined(QD_TILE_PAD_LDS)
+    char pad[QD_TILE_PAD_LDS];                 // diagnostic builds: occupancy sensitivity
+#endif
 };
 
 __device__ __forceinline__ double qd_rl(double v, int lane) {                       // uniform lane index
