@@ -383,18 +383,32 @@ static int qd_launch_ground(qd_handle* h, const int32_t* env_ids, int base, int 
         QD_HIP(hipGetLastError());
         }
         if (stages & 2) {
-        QD_HIP(hipEventRecord(h->ev_fork, s));
-        QD_HIP(hipStreamWaitEvent(h->side, h->ev_fork, 0));
-        QD_HIP(hipStreamWaitEvent(h->side2, h->ev_fork, 0));
-        QD_HIP(qd_launch_solve<9>(h, h->side));
-        QD_HIP(hipEventRecord(h->ev_join, h->side));
-        QD_HIP(qd_launch_solve<8>(h, h->side2)); QD_HIP(qd_launch_solve<7>(h, h->side2)); QD_HIP(qd_launch_solve<6>(h, h->side2));
-        QD_HIP(qd_launch_solve<5>(h, h->side2)); QD_HIP(qd_launch_solve<4>(h, h->side2));
-        QD_HIP(hipEventRecord(h->ev_join2, h->side2));
+        // A hop component lies in one total-charge sector of the kept states: at most 4 states for 2 dots (16 candidates), 12 for
+        // 3 dots; the launches of size classes that cannot occur are skipped.  Small launches (launch-bound: config 1) stay on one
+        // stream; large ones put the memory solver of the rare 13..32-state blocks (one long latency chain) and the wide register
+        // solvers on two side streams.
+        const int max_bin = h->N == 2 ? qd_gs_bin(4) : (h->N == 3 ? qd_gs_bin(12) : QD_GS_NBIN - 1);
+        const bool forked = batches >= 2048;
+        hipStream_t s9 = forked ? h->side : s, s48 = forked ? h->side2 : s;
+        if (forked) {
+            QD_HIP(hipEventRecord(h->ev_fork, s));
+            QD_HIP(hipStreamWaitEvent(h->side, h->ev_fork, 0));
+            QD_HIP(hipStreamWaitEvent(h->side2, h->ev_fork, 0));
+        }
+        if (max_bin >= 9) QD_HIP(qd_launch_solve<9>(h, s9));
+        if (forked) QD_HIP(hipEventRecord(h->ev_join, h->side));
+        if (max_bin >= 8) QD_HIP(qd_launch_solve<8>(h, s48));
+        if (max_bin >= 7) QD_HIP(qd_launch_solve<7>(h, s48));
+        if (max_bin >= 6) QD_HIP(qd_launch_solve<6>(h, s48));
+        if (max_bin >= 5) QD_HIP(qd_launch_solve<5>(h, s48));
+        if (max_bin >= 4) QD_HIP(qd_launch_solve<4>(h, s48));
+        if (forked) QD_HIP(hipEventRecord(h->ev_join2, h->side2));
         QD_HIP(qd_launch_solve<0>(h, s)); QD_HIP(qd_launch_solve<1>(h, s)); QD_HIP(qd_launch_solve<2>(h, s));
-        QD_HIP(qd_launch_solve<3>(h, s));
-        QD_HIP(hipStreamWaitEvent(s, h->ev_join, 0));
-        QD_HIP(hipStreamWaitEvent(s, h->ev_join2, 0));
+        if (max_bin >= 3) QD_HIP(qd_launch_solve<3>(h, s));
+        if (forked) {
+            QD_HIP(hipStreamWaitEvent(s, h->ev_join, 0));
+            QD_HIP(hipStreamWaitEvent(s, h->ev_join2, 0));
+        }
         }
         if (stages & 4) {
         if (h->eig) {
