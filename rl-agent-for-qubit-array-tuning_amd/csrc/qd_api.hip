@@ -132,10 +132,10 @@ extern "C" int qd_create(const qd_config* cfg, int device, qd_handle** out) {
     // scratch in flight per launch, sized for 288 GB of HBM: candidate records (488 B / pixel) + the ground-state slabs
     // (worst case 5.7 KB / pixel: a pixel whose 32 states form ONE hop component needs a 528-double block) -- 64 GiB, i.e.
     // 388 envs of the 8-dot 64x64 headline per launch (measured, whole bench: 20 GiB 9 070, 40 GiB 9 670, 64 GiB 9 950 env-steps/s),
-    // but never more than a quarter of what is free on the device right now
+    // but never more than a third of what is free on the device right now
     size_t budget = (size_t)64 << 30, free_b = 0, total_b = 0;
     if (const char* gib = getenv("QDSIM_SCRATCH_GIB")) { const long g = atol(gib); if (g > 0) budget = (size_t)g << 30; }   // (sizing experiments)
-    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b / 4 < budget) budget = free_b / 4;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b / 3 < budget) budget = free_b / 3;
     int chunk = cfg->env_chunk, gs_chunk;
     if (val) {
         // validate mode keeps every env's records (qd_get_candidates); only the slabs are chunked

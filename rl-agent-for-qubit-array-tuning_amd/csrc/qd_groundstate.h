@@ -29,7 +29,9 @@
 
 #if defined(__HIPCC__)
 
-#define QD_NBMAX 14                 // a state has at most 2*(N-1) hop neighbours
+#ifndef QD_NBREG
+#define QD_NBREG 2                  // neighbour slots kept in registers; the other 2*(N-1) - 2 live in LDS (8 dots: 31 KB per block, 5 blocks per CU)
+#endif
 #define QD_GS_BLOCK 256
 #define QD_GS_PPB 256               // pixels per batch (4 waves x 32 iterations x 2 pixels)
 // size classes: 2 .. 8 states exactly, 9-10 (solved as 10), 11-12 (as 12), 13-32 (memory solver)
@@ -46,9 +48,11 @@ typedef __attribute__((address_space(3))) double qd_lds_double;
 typedef volatile qd_lds_double* qd_lds_vptr;
 typedef const volatile qd_lds_double* qd_lds_cvptr;
 
+template <int N>
 struct QdWaveLds {
-    double coef[QD_NBMAX][64];      // H_ij of neighbour slot s of lane
-    unsigned char nidx[QD_NBMAX][64];
+    static constexpr int NS = (2 * (N - 1) - QD_NBREG) > 1 ? (2 * (N - 1) - QD_NBREG) : 1;   // a state has at most 2*(N-1) hop neighbours
+    double coef[NS][64];            // H_ij of neighbour slot QD_NBREG + s of lane
+    unsigned char nidx[NS][64];
     double buf[64];                 // publish buffer for per-component reductions
     double pv[2][16];               // per half: tc[0..N-2] at offset 9
     short pfl[2][8];                // per half: floor(n_cont)
@@ -121,7 +125,7 @@ __device__ __forceinline__ int qd_wave_max_int(int v) {
 // ps: the pixel's slot in the batch; live: false for the clamped duplicate beyond the image (nothing is emitted).
 // ---------------------------------------------------------------------------------------------------------------
 template <int N, bool VALIDATE>
-__device__ __forceinline__ void qd_ground_structure(const QdPixelRec* __restrict__ rec, bool live, int ps, QdWaveLds& W,
+__device__ __forceinline__ void qd_ground_structure(const QdPixelRec* __restrict__ rec, bool live, int ps, QdWaveLds<N>& W,
                                                     QdBlockLds& S, const QdSlab& sl) {
     const int lane = threadIdx.x & 63;
     const int m = lane & 31;
@@ -192,6 +196,9 @@ __device__ __forceinline__ void qd_ground_structure(const QdPixelRec* __restrict
     const int cnt = __popc(nbrmask);
     const int maxcnt = qd_wave_max_int(cnt);
     double radius = 0.0;
+    double creg[QD_NBREG]; int jreg[QD_NBREG];
+#pragma unroll
+    for (int i = 0; i < QD_NBREG; ++i) { creg[i] = 0.0; jreg[i] = m; }
     {
         unsigned rem = nbrmask;
         for (int s = 0; s < maxcnt; ++s) {
@@ -216,7 +223,10 @@ __device__ __forceinline__ void qd_ground_structure(const QdPixelRec* __restrict
                 if (prod > 0.0) sq_ = qd_sqrt1(prod);
                 c = -t * sq_;
             }
-            W.coef[s][lane] = c; W.nidx[s][lane] = (unsigned char)j;
+            if (s < QD_NBREG) {                            // (s is uniform: scalar branches)
+#pragma unroll
+                for (int i = 0; i < QD_NBREG; ++i) if (i == s) { creg[i] = c; jreg[i] = j; }
+            } else { W.coef[s - QD_NBREG][lane] = c; W.nidx[s - QD_NBREG][lane] = (unsigned char)j; }
             radius += fabs(c);
         }
     }
@@ -284,9 +294,12 @@ __device__ __forceinline__ void qd_ground_structure(const QdPixelRec* __restrict
         unsigned nrm = 0;                                  // ranks that carry a coupling
         for (int s = 0; s < maxcnt; ++s) {
             if (s < cnt && solve) {
-                const int j = (int)W.nidx[s][lane];
+                int j = jreg[0]; double c = creg[0];
+                if (s >= QD_NBREG) { j = (int)W.nidx[s - QD_NBREG][lane]; c = W.coef[s - QD_NBREG][lane]; }
+#pragma unroll
+                for (int i = 1; i < QD_NBREG; ++i) if (i == s) { j = jreg[i]; c = creg[i]; }
                 const int rj = __popc(seg & ((1u << j) - 1u));
-                if (rj < r) { row[rj] = W.coef[s][lane]; nrm |= 1u << rj; }
+                if (rj < r) { row[rj] = c; nrm |= 1u << rj; }
             }
         }
         for (int c = 0; c < smax - 1; ++c)

@@ -261,7 +261,7 @@ __device__ __forceinline__ void qd_gs_locate(const QdGsGeom& g, int batch, int& 
 }
 
 #ifndef QD_GS_WAVES
-#define QD_GS_WAVES 4            // <= 128 VGPRs and 4 x 36 KB of LDS per CU
+#define QD_GS_WAVES 5            // <= 96 VGPRs and 5 x 31 KB of LDS per CU (8 dots)
 #endif
 template <int N, bool VALIDATE>
 __global__ void __launch_bounds__(QD_GS_BLOCK, QD_GS_WAVES)
@@ -269,7 +269,7 @@ qd_k_gs_structure(const int* __restrict__ env_ids, int env_base, int rec_slot0, 
                   const QdPixelRec* __restrict__ recs, const double* __restrict__ state, int noise_flags,
                   unsigned char* __restrict__ slabs, unsigned* __restrict__ gtiles, unsigned* __restrict__ tilelist, size_t batches_cap) {
     const QdLayout L = qd_layout(N);
-    __shared__ QdWaveLds sW[QD_GS_BLOCK / 64];
+    __shared__ QdWaveLds<N> sW[QD_GS_BLOCK / 64];
     __shared__ QdBlockLds sB;
     const int batch = blockIdx.x;
     const QdSlab sl = qd_gs_slab(slabs + (size_t)batch * qd_gs_slab_bytes(VALIDATE), VALIDATE);
@@ -286,7 +286,7 @@ qd_k_gs_structure(const int* __restrict__ env_ids, int env_base, int rec_slot0, 
     const QdPixelRec* rbase = recs + ((size_t)(rec_slot0 + slot) * g.C + ch) * g.P;
     if (threadIdx.x <= QD_GS_NBIN) { if (threadIdx.x == 0) sB.pool_top = 0; else sB.cnt[threadIdx.x - 1] = 0; }
     __syncthreads();
-    QdWaveLds& W = sW[wave];
+    QdWaveLds<N>& W = sW[wave];
     for (int it = 0; it < QD_GS_PPB / 8; ++it) {
         const int ps = wave * (QD_GS_PPB / 4) + it * 2 + (lane >> 5);
         if (p0 + wave * (QD_GS_PPB / 4) + it * 2 >= g.P) break;                 // uniform for the wave
@@ -333,16 +333,25 @@ qd_k_gs_solve(unsigned char* __restrict__ slabs, const unsigned* __restrict__ gt
     const unsigned* tl = tilelist + qd_gs_tile_off(BIN, batches_cap);
     const unsigned nwaves = gridDim.x * 4u;
     unsigned gt = blockIdx.x * 4u + (threadIdx.x >> 6);
+    // Software pipeline over the wave's tiles: a tile's descriptor is fetched two tiles ahead and its task offsets one tile
+    // ahead, so only the loads of the block itself are waited for (the kernels are latency bound: waves wait > 80 % of the time).
+    const size_t slab_bytes = qd_gs_slab_bytes(VALIDATE);
+    auto offset_of = [&](unsigned d) -> unsigned {
+        const QdSlab sl = qd_gs_slab(slabs + (size_t)(d >> 12) * slab_bytes, VALIDATE);
+        return lane <= (int)(d & 63u) ? sl.lists[qd_gs_list_off(BIN) + (int)((d >> 6) & 63u) * 64 + lane] : 0u;
+    };
     unsigned desc = gt < ntile ? tl[gt] : 0u;
+    unsigned desc1 = gt + nwaves < ntile ? tl[gt + nwaves] : 0u;
+    unsigned off = gt < ntile ? offset_of(desc) : 0u;
     for (; gt < ntile; gt += nwaves) {
-        // the next tile's descriptor is fetched while this tile is solved (one dependent load less per tile)
-        const unsigned next = gt + nwaves < ntile ? tl[gt + nwaves] : 0u;
-        const unsigned batch = desc >> 12, t = (desc >> 6) & 63u;
+        const unsigned desc2 = gt + 2u * nwaves < ntile ? tl[gt + 2u * nwaves] : 0u;
+        const unsigned off1 = gt + nwaves < ntile ? offset_of(desc1) : 0u;
+        const unsigned batch = desc >> 12;
         const int here = (int)(desc & 63u) + 1;
-        desc = next;
-        const QdSlab sl = qd_gs_slab(slabs + (size_t)batch * qd_gs_slab_bytes(VALIDATE), VALIDATE);
+        const QdSlab sl = qd_gs_slab(slabs + (size_t)batch * slab_bytes, VALIDATE);
         int its = 0;
-        if (lane < here) its = qd_gs_solve_task<BIN, VALIDATE>(sl.pool + sl.lists[qd_gs_list_off(BIN) + (int)t * 64 + lane]);
+        if (lane < here) its = qd_gs_solve_task<BIN, VALIDATE>(sl.pool + off);
+        desc = desc1; desc1 = desc2; off = off1;
         if (VALIDATE && stats) {
             int sum = its, mx = its;
 #pragma unroll
