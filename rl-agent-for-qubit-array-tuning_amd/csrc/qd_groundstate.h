@@ -30,7 +30,7 @@
 #if defined(__HIPCC__)
 
 #ifndef QD_NBREG
-#define QD_NBREG 2                  // neighbour slots kept in registers; the other 2*(N-1) - 2 live in LDS (8 dots: 31 KB per block, 5 blocks per CU)
+#define QD_NBREG 6                  // neighbour slots kept in registers; the other 2*(N-1) - 6 live in LDS (8 dots: 21 KB per block)
 #endif
 #define QD_GS_BLOCK 256
 #define QD_GS_PPB 256               // pixels per batch (4 waves x 32 iterations x 2 pixels)

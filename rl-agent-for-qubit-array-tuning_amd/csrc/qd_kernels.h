@@ -261,7 +261,9 @@ __device__ __forceinline__ void qd_gs_locate(const QdGsGeom& g, int batch, int& 
 }
 
 #ifndef QD_GS_WAVES
-#define QD_GS_WAVES 5            // <= 96 VGPRs and 5 x 31 KB of LDS per CU (8 dots)
+#define QD_GS_WAVES 7            // 72 VGPRs (28 B of scratch per lane) and 7 x 21 KB of LDS per CU (8 dots).  The kernel is latency
+                                 // bound (ds_bpermute / LDS chains): measured per env-step 4 waves per SIMD 26.8 us, 5: 22.6, 6: 20.5, 7: 19.6,
+                                 // 8 (64 VGPRs, 116 B of scratch): 31.2
 #endif
 template <int N, bool VALIDATE>
 __global__ void __launch_bounds__(QD_GS_BLOCK, QD_GS_WAVES)
@@ -365,8 +367,11 @@ qd_k_gs_solve(unsigned char* __restrict__ slabs, const unsigned* __restrict__ gt
     }
 }
 
+#ifndef QD_SEL_WAVES
+#define QD_SEL_WAVES 3
+#endif
 template <int N, bool VALIDATE>
-__global__ void __launch_bounds__(QD_GS_BLOCK)
+__global__ void __launch_bounds__(QD_GS_BLOCK, QD_SEL_WAVES)
 qd_k_gs_select(const int* __restrict__ env_ids, int env_base, int rec_slot0, QdGsGeom g, int R, const double* __restrict__ params,
                const QdPixelRec* __restrict__ recs, double* __restrict__ zraw, double* __restrict__ occ_out,
                const double* __restrict__ state, int noise_flags, double* __restrict__ eig_out, unsigned char* __restrict__ slabs) {
