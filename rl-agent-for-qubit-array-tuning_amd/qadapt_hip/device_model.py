@@ -325,3 +325,23 @@ class DeviceSampler:
     @property
     def n_draws(self):
         return len(self.plan.lo)
+
+
+def check_solver_options(qconfig):
+    """`simulator.latched_model` of qarray_config.yaml (qarray_config.yaml:127-130 in the reference) selects how the
+    reference solves each pixel.  This library implements the default: 32 kept charge states and the EXACT ground state of
+    their Hamiltonian (the reference: dense `jnp.linalg.eigh`, ground_state.py:149-162).  Two options would silently give
+    other numbers than the reference and are refused instead:
+      * `use_sparse: true` -- the reference then approximates the ground state by 50 float32 Lanczos steps from the uniform
+        superposition at ONE representative tunnel coupling (fully_sparse_jax_eigensolver.py:68-133, ground_state.py:117-147);
+        that approximation is not built;
+      * `num_charge_states` other than 32 -- the kernels keep exactly 32 (QD_K).
+    `charge_state_batch_size` only chunks the reference's scan and does not change its result (any value is fine)."""
+    lm = ((qconfig or {}).get("simulator") or {}).get("latched_model") or {}
+    if lm.get("use_sparse"):
+        raise NotImplementedError("latched_model.use_sparse: true selects the reference's 50-step float32 Lanczos approximation "
+                                  "(fully_sparse_jax_eigensolver.py:68-133); qadapt_hip only computes the exact ground state "
+                                  "(the default, use_sparse: false)")
+    k = lm.get("num_charge_states", 32)
+    if k is not None and int(k) != 32:
+        raise NotImplementedError(f"latched_model.num_charge_states = {k}: the kernels keep exactly 32 charge states")

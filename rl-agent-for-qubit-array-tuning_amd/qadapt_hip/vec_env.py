@@ -20,7 +20,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .device_model import DeviceSampler, load_yaml
+from .device_model import DeviceSampler, check_solver_options, load_yaml
 from .layout import layout
 
 
@@ -61,6 +61,7 @@ class VecQuantumDeviceEnv:
         self.env_id_offset = int(env_id_offset)
         self.config = load_yaml(config_path, "env_config.yaml")
         self.qconfig = load_yaml(qarray_config_path, "qarray_config.yaml")
+        check_solver_options(self.qconfig)
         if voltage_capacitance_model is not None:
             self.qconfig["simulator"]["voltage_capacitance_model"]["type"] = \
                 None if voltage_capacitance_model in ("none", "null") else voltage_capacitance_model

@@ -63,3 +63,21 @@ def test_reference_yaml_files_parse_to_same_plan():
 def test_missing_config_raises_filenotfound():
     with pytest.raises(FileNotFoundError):
         DM.load_yaml("/nonexistent/env.yaml", "env_config.yaml")
+
+
+def test_solver_options_that_would_change_the_numbers_are_refused():
+    """`latched_model.use_sparse` selects a 50-step float32 Lanczos approximation in the reference; accepting the
+    flag and returning the exact answer would silently differ, so it is refused (as is a kept-state count other than 32)."""
+    import pytest
+    from qadapt_hip import device_model as DM
+    q = DM.load_yaml(None, "qarray_config.yaml")
+    DM.check_solver_options(q)                                         # the shipped defaults pass
+    q["simulator"]["latched_model"]["charge_state_batch_size"] = 250   # chunking only: fine
+    DM.check_solver_options(q)
+    q["simulator"]["latched_model"]["use_sparse"] = True
+    with pytest.raises(NotImplementedError, match="use_sparse"):
+        DM.check_solver_options(q)
+    q["simulator"]["latched_model"]["use_sparse"] = False
+    q["simulator"]["latched_model"]["num_charge_states"] = 64
+    with pytest.raises(NotImplementedError, match="32"):
+        DM.check_solver_options(q)
