@@ -9,8 +9,20 @@
 #include "qdsim.h"
 #include "qd_kernels.h"
 
+// Scratch + streams of one launch chunk in flight.  Product mode keeps TWO: consecutive chunks alternate between them on
+// two internal streams, so the candidate search of one chunk (float64 VALU bound) runs beside the ground-state stage of
+// the other (its solve / select launches wait on memory most of the time).
+#define QD_MAX_LANES 4
+struct QdLane {
+    QdPixelRec* recs; unsigned char* slabs; unsigned* gtiles;
+    hipStream_t run, side, side2;
+    hipEvent_t ev_fork, ev_join, ev_join2, ev_done;
+};
+
 struct qd_handle {
     qd_config cfg;
+    QdLane lanes[QD_MAX_LANES]; int nlanes;            // (the fields recs / slabs / gtiles / side / ev_* below are the lane in use)
+    hipEvent_t ev_start;
     int device;
     QdLayout L;
     int N, R, B, C, P;
@@ -37,6 +49,12 @@ struct qd_handle {
     unsigned long long obs_serial;
     char err[512];
 };
+
+static void qd_use_lane(qd_handle* h, int k) {
+    const QdLane& ln = h->lanes[k];
+    h->recs = ln.recs; h->slabs = ln.slabs; h->gtiles = ln.gtiles;
+    h->side = ln.side; h->side2 = ln.side2; h->ev_fork = ln.ev_fork; h->ev_join = ln.ev_join; h->ev_join2 = ln.ev_join2;
+}
 
 static int qd_fail(qd_handle* h, int code, const char* what, hipError_t e = hipSuccess) {
     if (h) {
@@ -137,6 +155,7 @@ extern "C" int qd_create(const qd_config* cfg, int device, qd_handle** out) {
     if (const char* gib = getenv("QDSIM_SCRATCH_GIB")) { const long g = atol(gib); if (g > 0) budget = (size_t)g << 30; }   // (sizing experiments)
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b / 3 < budget) budget = free_b / 3;
     int chunk = cfg->env_chunk, gs_chunk;
+    h->nlanes = 1;
     if (val) {
         // validate mode keeps every env's records (qd_get_candidates); only the slabs are chunked
         chunk = h->B;
@@ -144,11 +163,13 @@ extern "C" int qd_create(const qd_config* cfg, int device, qd_handle** out) {
         gs_chunk = (int)(g < 1 ? 1 : (g > (size_t)h->B ? (size_t)h->B : g));
         if (cfg->env_chunk > 0 && cfg->env_chunk < gs_chunk) gs_chunk = cfg->env_chunk;
     } else {
+        h->nlanes = 2;
+        if (const char* ls = getenv("QDSIM_LANES")) { const int l = atoi(ls); if (l >= 1 && l <= QD_MAX_LANES) h->nlanes = l; }   // (experiments)
         if (chunk <= 0) {
-            size_t g = budget / (per_env_rec + per_env_slab);
+            size_t g = budget / h->nlanes / (per_env_rec + per_env_slab);   // the lanes share the budget
             chunk = (int)(g < 1 ? 1 : g);
         }
-        if (chunk > h->B) chunk = h->B;
+        if (chunk >= h->B) { chunk = h->B; h->nlanes = 1; }           // one launch covers the batch: nothing to overlap
         gs_chunk = chunk;
     }
     // (tile descriptors carry the batch number in 20 bits)
@@ -169,7 +190,18 @@ extern "C" int qd_create(const qd_config* cfg, int device, qd_handle** out) {
     QD_HIP(hipMalloc(&h->steps, sizeof(int) * (size_t)h->B));
     QD_HIP(hipMalloc(&h->zraw, sizeof(double) * (size_t)h->B * h->C * h->P));
     QD_HIP(hipMalloc(&h->plohi, sizeof(double) * 2 * (size_t)h->B));
-    QD_HIP(hipMalloc(&h->recs, per_env_rec * h->recs_envs));
+    QD_HIP(hipEventCreateWithFlags(&h->ev_start, hipEventDisableTiming));
+    for (int k = 0; k < h->nlanes; ++k) {
+        QdLane& ln = h->lanes[k];
+        QD_HIP(hipMalloc(&ln.recs, per_env_rec * h->recs_envs));
+        QD_HIP(hipStreamCreateWithFlags(&ln.run, hipStreamNonBlocking));
+        QD_HIP(hipStreamCreateWithFlags(&ln.side, hipStreamNonBlocking));
+        QD_HIP(hipStreamCreateWithFlags(&ln.side2, hipStreamNonBlocking));
+        QD_HIP(hipEventCreateWithFlags(&ln.ev_fork, hipEventDisableTiming));
+        QD_HIP(hipEventCreateWithFlags(&ln.ev_join, hipEventDisableTiming));
+        QD_HIP(hipEventCreateWithFlags(&ln.ev_join2, hipEventDisableTiming));
+        QD_HIP(hipEventCreateWithFlags(&ln.ev_done, hipEventDisableTiming));
+    }
     h->tel_words = (h->P + 63) / 64;
     if (cfg->noise_flags & QD_NOISE_SENSOR) {
         QD_HIP(hipMalloc(&h->tel, sizeof(unsigned long long) * (size_t)h->B * h->C * h->tel_words));
@@ -180,13 +212,11 @@ extern "C" int qd_create(const qd_config* cfg, int device, qd_handle** out) {
     // the tile-shared search pays off where neighbouring pixels are close in voltage (fine grids) and needs >= 32
     // candidates valid across a tile (N >= 4); otherwise every pixel is searched on its own
     h->tile_search = (h->N >= 4 && h->R >= 32 && !(cfg->flags & QD_FLAG_PIXEL_SEARCH)) ? 1 : 0;
-    QD_HIP(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
-    QD_HIP(hipStreamCreateWithFlags(&h->side2, hipStreamNonBlocking));
-    QD_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
-    QD_HIP(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
-    QD_HIP(hipEventCreateWithFlags(&h->ev_join2, hipEventDisableTiming));
-    QD_HIP(hipMalloc(&h->slabs, h->gs_batches * qd_gs_slab_bytes(val)));
-    QD_HIP(hipMalloc(&h->gtiles, sizeof(unsigned) * (16 + qd_gs_tile_off(QD_GS_NBIN, h->gs_batches))));
+    for (int k = 0; k < h->nlanes; ++k) {
+        QD_HIP(hipMalloc(&h->lanes[k].slabs, h->gs_batches * qd_gs_slab_bytes(val)));
+        QD_HIP(hipMalloc(&h->lanes[k].gtiles, sizeof(unsigned) * (16 + qd_gs_tile_off(QD_GS_NBIN, h->gs_batches))));
+    }
+    qd_use_lane(h, 0);
     if (cfg->flags & QD_FLAG_VALIDATE) {
         QD_HIP(hipMalloc(&h->tstats, sizeof(unsigned long long) * 32));
         QD_HIP(hipMemset(h->tstats, 0, sizeof(unsigned long long) * 32));
@@ -218,18 +248,25 @@ extern "C" int qd_create(const qd_config* cfg, int device, qd_handle** out) {
 extern "C" int qd_destroy(qd_handle* h) {
     if (!h) return QD_ERR_ARG;
     QdDeviceGuard guard_(h->device);
-    void* bufs[] = {h->params, h->state, h->steps, h->zraw, h->plohi, h->recs, h->occ, h->tel, h->eig, h->tstats, h->slabs, h->gtiles};
+    void* bufs[] = {h->params, h->state, h->steps, h->zraw, h->plohi, h->occ, h->tel, h->eig, h->tstats};
     for (void* b : bufs) if (b) (void)hipFree(b);
+    for (int k = 0; k < QD_MAX_LANES; ++k) {
+        void* lb[] = {h->lanes[k].recs, h->lanes[k].slabs, h->lanes[k].gtiles};
+        for (void* b : lb) if (b) (void)hipFree(b);
+    }
     for (int k = 0; k < 2; ++k) {
         if (h->stage_busy[k]) (void)hipEventSynchronize(h->stage_ev[k]);
         if (h->stage[k]) (void)hipHostFree(h->stage[k]);
         if (h->stage_ev[k]) (void)hipEventDestroy(h->stage_ev[k]);
     }
-    if (h->side) (void)hipStreamDestroy(h->side);
-    if (h->side2) (void)hipStreamDestroy(h->side2);
-    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
-    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
-    if (h->ev_join2) (void)hipEventDestroy(h->ev_join2);
+    for (int k = 0; k < QD_MAX_LANES; ++k) {
+        QdLane& ln = h->lanes[k];
+        hipStream_t st[] = {ln.run, ln.side, ln.side2};
+        for (hipStream_t q : st) if (q) (void)hipStreamDestroy(q);
+        hipEvent_t evs[] = {ln.ev_fork, ln.ev_join, ln.ev_join2, ln.ev_done};
+        for (hipEvent_t ev : evs) if (ev) (void)hipEventDestroy(ev);
+    }
+    if (h->ev_start) (void)hipEventDestroy(h->ev_start);
     delete h;
     return QD_OK;
 }
@@ -474,10 +511,30 @@ extern "C" int qd_observe(qd_handle* h, const int32_t* env_ids, int n, void* str
         qd_k_telegraph<<<dim3((nt + 63) / 64), dim3(64), 0, s>>>(env_ids, n, h->C, h->P, L.size, L.noise, h->params, h->tel, qd_noise_cfg(h));
         QD_HIP(hipGetLastError());
     }
-    for (int base = 0; base < n; base += h->chunk) {
-        const int cnt = (n - base < h->chunk) ? n - base : h->chunk;
-        int rc = qd_launch_csd(h, env_ids, base, cnt, s, 3);
-        if (rc) return rc;
+    if (h->nlanes == 1 || n <= h->chunk) {
+        qd_use_lane(h, 0);
+        for (int base = 0; base < n; base += h->chunk) {
+            const int cnt = (n - base < h->chunk) ? n - base : h->chunk;
+            int rc = qd_launch_csd(h, env_ids, base, cnt, s, 3);
+            if (rc) return rc;
+        }
+    } else {
+        // consecutive chunks go round the lanes (own scratch, own stream): search and ground state of different chunks overlap
+        QD_HIP(hipEventRecord(h->ev_start, s));
+        for (int k = 0; k < h->nlanes; ++k) QD_HIP(hipStreamWaitEvent(h->lanes[k].run, h->ev_start, 0));
+        int i = 0;
+        for (int base = 0; base < n; base += h->chunk, ++i) {
+            const int cnt = (n - base < h->chunk) ? n - base : h->chunk;
+            const int ln = i % h->nlanes;
+            qd_use_lane(h, ln);
+            int rc = qd_launch_csd(h, env_ids, base, cnt, h->lanes[ln].run, 3);
+            if (rc) { qd_use_lane(h, 0); return rc; }
+        }
+        qd_use_lane(h, 0);
+        for (int k = 0; k < h->nlanes; ++k) {
+            QD_HIP(hipEventRecord(h->lanes[k].ev_done, h->lanes[k].run));
+            QD_HIP(hipStreamWaitEvent(s, h->lanes[k].ev_done, 0));
+        }
     }
     if (h->cfg.noise_flags & QD_NOISE_LATCH) {
         const int nt = n * h->C;
