@@ -522,6 +522,8 @@ extern "C" int qd_observe(qd_handle* h, const int32_t* env_ids, int n, void* str
         // consecutive chunks go round the lanes (own scratch, own stream): search and ground state of different chunks overlap
         QD_HIP(hipEventRecord(h->ev_start, s));
         for (int k = 0; k < h->nlanes; ++k) QD_HIP(hipStreamWaitEvent(h->lanes[k].run, h->ev_start, 0));
+        // (measured: 2 lanes 11 520 env-steps/s, 3 lanes 10 920, 4 lanes 11 350; starting the second lane half a chunk out of
+        // phase: 11 310 against 11 620 in the same run)
         int i = 0;
         for (int base = 0; base < n; base += h->chunk, ++i) {
             const int cnt = (n - base < h->chunk) ? n - base : h->chunk;
