@@ -322,6 +322,11 @@ __device__ __forceinline__ int qd_eig_task(double* rec) {
     for (int i = 0; i < S; ++i) if (i < sz) rec[2 + i] = x[i];
     return its;
 }
+// Blocks of 13..32 states (0.1 % of the pixels have one): the same algorithm with run-time loops in the task's record -- a serial
+// O(s^3) chain of dependent memory operations, ~1 ms per wave whatever the batch, run on a side stream.  Measured and not kept
+// (bench, env-steps/s; this version 11 500-11 600): solving blocks of <= 16 states in an LDS tile ([element][lane], 100 KB per
+// wave, one wave per CU): 11 000-11 100 (a tenth of the latency per operation, a twentieth of the waves in flight); listing the
+// class's single tasks launch-wide so that its waves are full: 11 400 (64 different records per memory instruction).
 template <bool VALIDATE>
 __device__ __forceinline__ int qd_eig_task_mem(double* rec) {
     const int s = (int)rec[1];

@@ -592,9 +592,11 @@ qd_k_tile(const int* __restrict__ env_ids, int env_base, int R, const double* __
     for (int k = 0; k < QD_K; ++k) {
         const uint32_t code = T.scode[T.u.k.id[k][lane]];
         const uint32_t dg = (code + off) - 0x44444444u;                       // nibbles: c - fl + 1 in 0..3 (no carries: each sum < 16)
-        unsigned idx = 0;
-#pragma unroll
-        for (int i = 0; i < N; ++i) idx |= ((dg >> (4 * (N - 1 - i))) & 3u) << (2 * (N - 1 - i));
+        // 2-bit digits at 4-bit spacing -> packed base-4 index (dot 0 most significant): three mask-shift steps
+        unsigned idx = dg & 0x33333333u;
+        idx = (idx | (idx >> 2)) & 0x0F0F0F0Fu;
+        idx = (idx | (idx >> 4)) & 0x00FF00FFu;
+        idx = (idx | (idx >> 8)) & 0x0000FFFFu;
         rec->idx[k] = (uint16_t)idx;
         const double E = sort_output ? T.u.k.e[k][lane] : T.u.k.e[k][lane] + Ecg;
         rec->E[k] = E * isa;
