@@ -70,8 +70,10 @@ typedef struct qd_config {
     double kalman_prior_mean_nnn; /* env.py:786                                    */
     double kalman_variance_threshold; /* capacitance_model.variance_threshold     */
     double kalman_process_noise;  /* capacitance_model.process_noise               */
-    uint64_t rng_seed;            /* Philox key for the stochastic stages          */
-    int64_t env_id_offset;        /* global id of env 0 (multi-GPU shards)         */
+    uint64_t rng_seed;            /* Philox key for the stochastic stages; the two 32-bit halves are XOR-folded into ONE
+                                     32-bit key word (seeds that differ only by such a fold give the same streams)      */
+    int64_t env_id_offset;        /* global id of env 0 (multi-GPU shards); the second key word is the low 32 bits of
+                                     env_id_offset + env index: global env ids are taken modulo 2^32                    */
     /* config variants reachable from env_config.yaml (env.py:393-441, 553-563, 592-618, 861-876) */
     int32_t use_deltas;           /* simulator.use_deltas: gate actions are increments (env.py:864-867) */
     int32_t sparse_reward;        /* reward.sparse_reward (env.py:393-414)         */
@@ -103,6 +105,8 @@ int qd_layout_query(int n_dot, int32_t* out31);
 
 /* QuantumDeviceEnv.__init__ (env.py:38-132): allocates device state for B envs
  * on GPU `device`; Kalman filters start at their priors (env.py:779-787). */
+/* On failure after the handle was allocated (QD_ERR_HIP / QD_ERR_NOMEM), *out is still set: read the message with
+ * qd_last_error and release the partial handle with qd_destroy. */
 int qd_create(const qd_config* cfg, int device, qd_handle** out);
 int qd_destroy(qd_handle* h);
 const char* qd_last_error(const qd_handle* h);

@@ -165,6 +165,10 @@ qd_k_tile(const int* __restrict__ env_ids, int env_base, int R, const double* __
 #pragma unroll
     for (int i = 0; i < N; ++i) fl[i] = (int)floor(ncont[i]);
 
+#if defined(QD_TILE_STOP) && QD_TILE_STOP == 1
+    if (inside) rec->E[0] = ncont[0] + vd[N - 1] + tc[0] + (double)fl[1];                 // diagnostic build: time split of the kernel (scripts/ab_build.sh)
+    return;
+#endif
     // ---- 2. tile geometry and the affine model of v' ------------------------------------------
     const int xr = min(tx * 8 + 3, R - 1), yr = min(ty * 8 + 3, R - 1);  // reference pixel = lane 27 (clamped)
     const double xs = (double)(x - xr), ys = (double)(y - yr);
@@ -224,6 +228,10 @@ qd_k_tile(const int* __restrict__ env_ids, int env_base, int R, const double* __
     if (allvalid_count < (unsigned long long)QD_K) { fail = true; why = 1; }
     __builtin_amdgcn_wave_barrier();
 
+#if defined(QD_TILE_STOP) && QD_TILE_STOP == 2
+    if (inside) rec->E[0] = rho + v0[0];                 // diagnostic build: time split of the kernel (scripts/ab_build.sh)
+    return;
+#endif
     // ---- 3. greedy lattice point cg (uniform), option costs, product set of seeds -------------------
     double Tpp = INFINITY, pn_ref = 0.0, margin = 0.0, Ecg = 0.0;
     if (!fail) {
@@ -354,6 +362,10 @@ qd_k_tile(const int* __restrict__ env_ids, int env_base, int R, const double* __
         }
     }
 
+#if defined(QD_TILE_STOP) && QD_TILE_STOP == 3
+    if (inside) rec->E[0] = Tpp + pn_ref + margin + Ecg;                 // diagnostic build: time split of the kernel (scripts/ab_build.sh)
+    return;
+#endif
     // ---- 4. level-synchronous branch and bound -------------------------------------------------
     int nfront = 0, cur = 0;
     if (!fail) {
@@ -408,6 +420,10 @@ qd_k_tile(const int* __restrict__ env_ids, int env_base, int R, const double* __
         }
     }
 
+#if defined(QD_TILE_STOP) && QD_TILE_STOP == 4
+    if (inside) rec->E[0] = (double)nfront + T.u.f.pn[cur][lane];                 // diagnostic build: time split of the kernel (scripts/ab_build.sh)
+    return;
+#endif
     // ---- 5. T (bisection on the count of maxima) and the superset S --------------------------------
     int nS = 0, nSfront = 0;
     if (!fail && nfront < QD_K) { fail = true; why = 4; }
@@ -492,6 +508,10 @@ qd_k_tile(const int* __restrict__ env_ids, int env_base, int R, const double* __
         return;
     }
 
+#if defined(QD_TILE_STOP) && QD_TILE_STOP == 5
+    if (inside) rec->E[0] = (double)nS + T.sD[lane];                 // diagnostic build: time split of the kernel (scripts/ab_build.sh)
+    return;
+#endif
     // ---- 6. per lane: energies of S, own validity box, 32 lowest ------------------------------------
     uint32_t blo = 0, bhi = 0;
 #pragma unroll
@@ -551,6 +571,10 @@ qd_k_tile(const int* __restrict__ env_ids, int env_base, int R, const double* __
     if (!inside) return;
     if (redo) { rec->nvalid = QD_T_REDO; return; }
 
+#if defined(QD_TILE_STOP) && QD_TILE_STOP == 6
+    if (inside) rec->E[0] = maxE + eout + (double)count;                 // diagnostic build: time split of the kernel (scripts/ab_build.sh)
+    return;
+#endif
     // ---- 7. the record ---------------------------------------------------------------------------------------
     {
     // reference index: digit = c - floor + 1 in base 4, dot 0 most significant

@@ -136,7 +136,12 @@ class VecQuantumDeviceEnv:
                             barrier_radius=float(rew.get("barrier_radius", 0.0)))
         self._h = ctypes.c_void_p()
         rc = self._lib.qd_create(ctypes.byref(cfg), self.device.index, ctypes.byref(self._h))
-        _lib.check(self._h, rc, "qd_create")
+        if rc != 0:                          # a partially built handle carries the error text and must be released
+            msg = self._lib.qd_last_error(self._h).decode() if self._h else "no handle"
+            if self._h:
+                self._lib.qd_destroy(self._h)
+                self._h = None
+            raise _lib.QdError(f"qd_create failed (code {rc}): {msg}")
         self.validate = bool(validate)
         # ---- caller-owned output tensors ---------------------------------------
         dev = self.device
