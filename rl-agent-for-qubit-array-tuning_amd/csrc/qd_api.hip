@@ -472,7 +472,7 @@ static int qd_launch_ground(qd_handle* h, const int32_t* env_ids, int base, int 
     }
 
 // a5-a13 for `cnt` envs starting at list position `base`.
-//   tile_search 1: tile search + exact redo pass, then qd_k_ground;  0: per-pixel search, then qd_k_ground.
+//   tile_search 1: tile search + exact redo pass, then the ground-state kernels;  0: per-pixel search, then the ground-state kernels.
 static int qd_launch_csd(qd_handle* h, const int32_t* env_ids, int base, int cnt, hipStream_t s, int what /*1 search, 2 ground, 3 both*/,
                          int parts = 0 /*timing hooks only: 1 tile search alone, 2 redo pass alone; 4/8/16 structure / solve / select alone*/) {
     const size_t shm = (size_t)QD_K * QD_CAND_BLOCK * (sizeof(double) + sizeof(uint16_t));

@@ -468,7 +468,7 @@ __global__ void qd_k_latch(const int* __restrict__ env_ids, int n_env, int R, co
 
 // ---------------------------------------------------------------------------
 // a15 + a16: sensor stage, one pixel per lane, in place on zraw.
-//   in : c0 from qd_k_ground      out: signal = sum_{k=-5..4} 1 / (((c0 + 2 a (k + eta)) / gamma)^2 + 1)
+//   in : c0 from qd_k_gs_select     out: signal = sum_{k=-5..4} 1 / (((c0 + 2 a (k + eta)) / gamma)^2 + 1)
 // eta = sensor-potential noise (white + telegraph), then radial image noise / replacement.
 // grid = (ceil(P/256), C, n_env)
 // ---------------------------------------------------------------------------

@@ -118,7 +118,7 @@ __device__ __forceinline__ void qd_tile_point(const QdTileLds& T, const double* 
 // stats (optional, 16 counters): tiles, tiles redone whole, lanes redone, sum of |S|, lanes redone for < 32 valid
 // states in S; [8 + reason]: tiles redone by reason (1 ranges, 2 seeds, 3 frontier overflow, 4 too few leaves, 5 |S|)
 // ---------------------------------------------------------------------------------------------
-// Writes one QdPixelRec per pixel for the ground-state kernel (qd_k_ground).
+// Writes one QdPixelRec per pixel for the ground-state kernels (qd_k_gs_*).
 template <int N>
 __global__ void __launch_bounds__(64)
 qd_k_tile(const int* __restrict__ env_ids, int env_base, int R, const double* __restrict__ params,

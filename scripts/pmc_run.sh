@@ -15,4 +15,4 @@ for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_
   rocprofv3 --pmc $set -d $out/p$i --output-format csv -- python3 scripts/kbench.py "$@" > $out/p$i.log 2>&1 || echo "pass $i failed"
 done
 python3 scripts/pmc_summary.py $out > $out/summary.csv
-grep "tile_cand\|qd_k_candidates\|qd_k_ground" $out/summary.csv
+grep "qd_k_tile\|qd_k_candidates\|qd_k_gs_" $out/summary.csv
