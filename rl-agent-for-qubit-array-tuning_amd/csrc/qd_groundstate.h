@@ -63,14 +63,17 @@ struct QdBlockLds {
 };
 
 // One batch's scratch in HBM/L2:
-//   pool   task records: [0] lambda (out), [1] residual (out; in: the size, for the padded / memory solvers),
+//   pool   task records: [0] unused, [1] residual (out, validate mode; in: the size, for the padded / memory solvers),
 //          [2 ..] packed lower triangle (in), overwritten by x[0..s-1] (out); blocks of > 12 states carry a 4 s workspace
 //          (+ a copy of the matrix in validate mode)
-//   link   per pixel and state: record offset of its component, QD_LINK_SINGLE or QD_LINK_NONE;  rank: index inside it
+//   link   per pixel and state: its component's position in `lists` (size classes back to back), QD_LINK_SINGLE or QD_LINK_NONE;
+//          rank: index inside the component
 //   lists  per size class: record offsets;  cnt: their lengths
+//   lam    the tasks' eigenvalues, dense, same index as `lists`: written coalesced by the solve launches and read by the select
+//          kernel with the locality of neighbouring pixels' tasks (reading them out of the records cost a 64-byte sector each)
 //   aux    validate mode, per pixel: ||H||_inf (scale of the residual), then the lowest free energy (offset of the eigenvalues)
 struct QdSlab {
-    double* pool; unsigned* link; unsigned char* rank; unsigned* lists; double* aux; unsigned* cnt;
+    double* pool; unsigned* link; unsigned char* rank; unsigned* lists; double* aux; unsigned* cnt; double* lam;
 };
 __host__ __device__ inline int qd_gs_list_cap(int bin) { return QD_GS_PPB * (32 / qd_gs_bin_min(bin)); }
 __host__ __device__ inline int qd_gs_list_off(int bin) { int o = 0; for (int b = 0; b < bin; ++b) o += qd_gs_list_cap(b); return o; }
@@ -87,6 +90,7 @@ __host__ __device__ inline size_t qd_gs_slab_bytes(bool validate) {
     b += (size_t)QD_GS_PPB * 16;                          // aux
     b += (size_t)QD_GS_PPB * 32;                          // rank
     b += 64;                                              // cnt
+    b += (size_t)qd_gs_list_off(QD_GS_NBIN) * 8;          // lam
     return (b + 255) & ~(size_t)255;
 }
 __host__ __device__ inline QdSlab qd_gs_slab(unsigned char* base, bool validate) {
@@ -96,7 +100,8 @@ __host__ __device__ inline QdSlab qd_gs_slab(unsigned char* base, bool validate)
     s.lists = (unsigned*)base; base += (size_t)qd_gs_list_off(QD_GS_NBIN) * 4;
     s.aux = (double*)base; base += (size_t)QD_GS_PPB * 16;
     s.rank = base; base += (size_t)QD_GS_PPB * 32;
-    s.cnt = (unsigned*)base;
+    s.cnt = (unsigned*)base; base += 64;
+    s.lam = (double*)base;
     return s;
 }
 // launch-wide tile lists: tile descriptor = batch << 12 | tile index inside the batch's list << 6 | tasks in the tile - 1
@@ -271,17 +276,18 @@ __device__ __forceinline__ void qd_ground_structure(const QdPixelRec* __restrict
 #endif
 
     // ---- 5. tasks: one record per surviving component ------------------------
-    unsigned base = 0;
+    unsigned base = 0, gi = 0;
     if (solve && r == 0) {
         base = atomicAdd(&S.pool_top, (unsigned)qd_gs_task_doubles(ssz, VALIDATE));
         const int bin = qd_gs_bin(ssz);
-        const unsigned pos = atomicAdd(&S.cnt[bin], 1u);
-        sl.lists[qd_gs_list_off(bin) + pos] = base;
+        gi = (unsigned)qd_gs_list_off(bin) + atomicAdd(&S.cnt[bin], 1u);
+        sl.lists[gi] = base;
         if (ssz > 8) sl.pool[base + 1] = (double)ssz;
     }
     base = (unsigned)__shfl((int)base, __builtin_ctz(seg), 32);
+    gi = (unsigned)__shfl((int)gi, __builtin_ctz(seg), 32);
     if (live) {
-        sl.link[ps * 32 + m] = solve ? base : (active ? QD_LINK_SINGLE : QD_LINK_NONE);
+        sl.link[ps * 32 + m] = solve ? gi : (active ? QD_LINK_SINGLE : QD_LINK_NONE);
         sl.rank[ps * 32 + m] = (unsigned char)r;
         if (VALIDATE) {
             const double hn = -qd_half_min(-(fabs(Fabs) + radius));       // ||H||_inf over the 32 states (unshifted)
@@ -312,12 +318,12 @@ __device__ __forceinline__ void qd_ground_structure(const QdPixelRec* __restrict
 // Phase B: one task per lane.  rec: the task's record in the slab.  Returns the Laguerre iterations (statistics).
 // ---------------------------------------------------------------------------------------------------------------
 template <int S, bool PADDED, bool VALIDATE>
-__device__ __forceinline__ int qd_eig_task(double* rec) {
-    double lam, resid, x[S];
+__device__ __forceinline__ int qd_eig_task(double* rec, double& lam) {
+    double resid, x[S];
     int its = 0;
     const int sz = PADDED ? (int)rec[1] : S;
     qd_eig_lowest<S, VALIDATE>(rec + 2, lam, x, resid, VALIDATE ? &its : nullptr, sz);
-    rec[0] = lam; rec[1] = resid;
+    if (VALIDATE) rec[1] = resid;                          // (the eigenvalue goes to the slab's dense array: qd_k_gs_solve)
 #pragma unroll
     for (int i = 0; i < S; ++i) if (i < sz) rec[2 + i] = x[i];
     return its;
@@ -328,17 +334,17 @@ __device__ __forceinline__ int qd_eig_task(double* rec) {
 // wave, one wave per CU): 11 000-11 100 (a tenth of the latency per operation, a twentieth of the waves in flight); listing the
 // class's single tasks launch-wide so that its waves are full: 11 400 (64 different records per memory instruction).
 template <bool VALIDATE>
-__device__ __forceinline__ int qd_eig_task_mem(double* rec) {
+__device__ __forceinline__ int qd_eig_task_mem(double* rec, double& lam) {
     const int s = (int)rec[1];
     const int ne = s * (s + 1) / 2;
     double* M = rec + 2;
     double* work = M + ne;
     double* copy = VALIDATE ? work + 4 * s : nullptr;
     if (VALIDATE) for (int e = 0; e < ne; ++e) copy[e] = M[e];
-    double lam, resid;
+    double resid;
     int its = 0;
     qd_eig_lowest_mem(s, M, work, copy, lam, resid, VALIDATE ? &its : nullptr);
-    rec[0] = lam; rec[1] = resid;
+    if (VALIDATE) rec[1] = resid;                          // (the eigenvalue goes to the slab's dense array: qd_k_gs_solve)
     for (int i = 0; i < s; ++i) M[i] = work[3 * s + i];
     return its;
 }
@@ -355,6 +361,7 @@ __device__ __forceinline__ void qd_ground_select(const QdPixelRec* __restrict__ 
     const unsigned* __restrict__ link = sl.link + ps * 32;
     const unsigned char* __restrict__ rank = sl.rank + ps * 32;
     const double* __restrict__ pool = sl.pool;
+    const double* __restrict__ lamd = sl.lam;
     const int nvalid = rec->nvalid;
     unsigned lk[QD_K];
     double lam[QD_K];
@@ -368,7 +375,7 @@ __device__ __forceinline__ void qd_ground_select(const QdPixelRec* __restrict__ 
 #pragma unroll
     for (int m = 0; m < QD_K; ++m) {
         const bool task = lk[m] < QD_LINK_SINGLE;
-        const double lt = pool[task ? lk[m] : 0u];         // (always a valid address; the value is used for tasks only)
+        const double lt = lamd[task ? lk[m] : 0u];         // (always a valid address; the value is used for tasks only)
         lam[m] = task ? lt : (lk[m] == QD_LINK_SINGLE ? 0.0 : INFINITY);
     }
     // the lowest component; tie between components (exactly equal energies): the state with the lowest candidate
@@ -388,6 +395,7 @@ __device__ __forceinline__ void qd_ground_select(const QdPixelRec* __restrict__ 
         if (better) { best = lam[m]; bestkey = key; wl = lk[m]; bm = m; }
     }
     const bool wtask = wl < QD_LINK_SINGLE;
+    const unsigned woff = wtask ? sl.lists[wl] : 0u;          // the winner's record
     // the winner's vector: one (predicated) load per member state
     unsigned rk8[QD_K / 4];
     {
@@ -401,7 +409,7 @@ __device__ __forceinline__ void qd_ground_select(const QdPixelRec* __restrict__ 
         const bool member = wtask ? (lk[m] == wl) : (m == bm);
         const unsigned rk = (rk8[m >> 2] >> (8 * (m & 3))) & 0xFFu;
         double x = 0.0;
-        if (member) x = wtask ? pool[wl + 2 + rk] : 1.0;
+        if (member) x = wtask ? pool[woff + 2 + rk] : 1.0;
         xs[m] = x;
     }
     int fl[N];
@@ -420,7 +428,7 @@ __device__ __forceinline__ void qd_ground_select(const QdPixelRec* __restrict__ 
     if (VALIDATE) {
         const double hn = sl.aux[ps];
         lam_out = best + sl.aux[QD_GS_PPB + ps];
-        if (wtask) resid_out = pool[wl + 1] / (hn > 0.0 ? hn : 1.0);
+        if (wtask) resid_out = pool[woff + 1] / (hn > 0.0 ? hn : 1.0);
     }
 }
 

@@ -317,11 +317,11 @@ qd_k_gs_structure(const int* __restrict__ env_ids, int env_base, int rec_slot0, 
 
 // size class -> solver
 template <int BIN, bool VALIDATE>
-__device__ __forceinline__ int qd_gs_solve_task(double* rec) {
-    if constexpr (BIN <= 6) return qd_eig_task<BIN + 2, false, VALIDATE>(rec);
-    else if constexpr (BIN == 7) return qd_eig_task<10, true, VALIDATE>(rec);
-    else if constexpr (BIN == 8) return qd_eig_task<12, true, VALIDATE>(rec);
-    else return qd_eig_task_mem<VALIDATE>(rec);
+__device__ __forceinline__ int qd_gs_solve_task(double* rec, double& lam) {
+    if constexpr (BIN <= 6) return qd_eig_task<BIN + 2, false, VALIDATE>(rec, lam);
+    else if constexpr (BIN == 7) return qd_eig_task<10, true, VALIDATE>(rec, lam);
+    else if constexpr (BIN == 8) return qd_eig_task<12, true, VALIDATE>(rec, lam);
+    else return qd_eig_task_mem<VALIDATE>(rec, lam);
 }
 // (register budgets: the unrolled solvers keep the whole packed block live -- 2: 36, 4: 98, 6: 168, 8: 248 VGPRs)
 template <int BIN> struct QdGsSolveWaves { static constexpr int v = BIN <= 1 ? 6 : (BIN == 2 ? 4 : (BIN == 3 ? 3 : (BIN <= 6 ? 2 : (BIN == 9 ? 4 : 1)))); };
@@ -352,7 +352,11 @@ qd_k_gs_solve(unsigned char* __restrict__ slabs, const unsigned* __restrict__ gt
         const int here = (int)(desc & 63u) + 1;
         const QdSlab sl = qd_gs_slab(slabs + (size_t)batch * slab_bytes, VALIDATE);
         int its = 0;
-        if (lane < here) its = qd_gs_solve_task<BIN, VALIDATE>(sl.pool + off);
+        if (lane < here) {
+            double lam;
+            its = qd_gs_solve_task<BIN, VALIDATE>(sl.pool + off, lam);
+            sl.lam[qd_gs_list_off(BIN) + (int)((desc >> 6) & 63u) * 64 + lane] = lam;         // dense, coalesced: what the select kernel reads
+        }
         desc = desc1; desc1 = desc2; off = off1;
         if (VALIDATE && stats) {
             int sum = its, mx = its;
