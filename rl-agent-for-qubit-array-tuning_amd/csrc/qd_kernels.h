@@ -202,7 +202,12 @@ qd_k_candidates(const int* __restrict__ env_ids, int env_base, int R, const doub
     // second pass behind the tile search (qd_tile.h): only the pixels it left to the exact per-pixel search
     if (only_flagged == 1 && rec->nvalid != QD_T_REDO) return;
     double vd[N], ncont[N], isa;
-    {
+    if (only_flagged == 1) {
+        // behind the tile search: the front end of this pixel is in the record already (qd_tile_hand_over)
+#pragma unroll
+        for (int i = 0; i < N; ++i) { ncont[i] = rec->E[i]; vd[i] = rec->E[8 + i]; }
+        isa = rec->E[16];
+    } else {
         double v_ext[V], vpp[G], tc[NB];
         qd_pixel_voltages<N>(spar, sst, ch, R, x, y, v_ext, vpp, tc);
         // the sensor stage wants the constant-matrix product: hand it over before v' is rescaled

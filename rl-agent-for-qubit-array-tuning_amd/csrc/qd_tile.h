@@ -113,6 +113,18 @@ __device__ __forceinline__ void qd_tile_point(const QdTileLds& T, const double* 
     }
 }
 
+// A pixel the tile search leaves to the exact per-pixel search: its front end is done already (v', the reference's 50-step
+// projected gradient: ~5 k instructions of the 44 k a redone tile costs), so the results travel in the record's energy slots
+// (E[0..N-1] = n_cont, E[8..8+N-1] = v', E[16] = 1 / s_a; rec->vpp / rec->tc are written by the front end) and the redo pass
+// (qd_k_candidates, only_flagged) starts at the search.  Same code, same bits.
+template <int N>
+__device__ __forceinline__ void qd_tile_hand_over(QdPixelRec* rec, const double* vd, const double* ncont, double isa) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) { rec->E[i] = ncont[i]; rec->E[8 + i] = vd[i]; }
+    rec->E[16] = isa;
+    rec->nvalid = QD_T_REDO;
+}
+
 // ---------------------------------------------------------------------------------------------
 // grid = (tiles, C, n_env), block = 64 (one wavefront = one 8x8 pixel tile)
 // stats (optional, 16 counters): tiles, tiles redone whole, lanes redone, sum of |S|, lanes redone for < 32 valid
@@ -504,7 +516,7 @@ qd_k_tile(const int* __restrict__ env_ids, int env_base, int R, const double* __
         atomicAdd(&stats[3], (unsigned long long)nS);
     }
     if (fail) {                                                            // the whole tile goes to the exact per-pixel search
-        if (inside) rec->nvalid = QD_T_REDO;
+        if (inside) qd_tile_hand_over<N>(rec, vd, ncont, isa);
         return;
     }
 
@@ -569,7 +581,7 @@ qd_k_tile(const int* __restrict__ env_ids, int env_base, int R, const double* __
         if (lane == 0 && rm) { atomicAdd(&stats[2], (unsigned long long)__builtin_popcountll(rm)); atomicAdd(&stats[4], (unsigned long long)__builtin_popcountll(rc)); }
     }
     if (!inside) return;
-    if (redo) { rec->nvalid = QD_T_REDO; return; }
+    if (redo) { qd_tile_hand_over<N>(rec, vd, ncont, isa); return; }
 
 #if defined(QD_TILE_STOP) && QD_TILE_STOP == 6
     if (inside) rec->E[0] = maxE + eout + (double)count;                 // diagnostic build: time split of the kernel (scripts/ab_build.sh)
