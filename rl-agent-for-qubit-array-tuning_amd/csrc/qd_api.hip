@@ -488,8 +488,13 @@ static int qd_launch_csd(qd_handle* h, const int32_t* env_ids, int base, int cnt
             QD_HIP(hipGetLastError());
         }
         if (parts != 1) {
-            QD_DISPATCH_N(h->N, qd_k_candidates<NN><<<g1, dim3(QD_CAND_BLOCK), shm, s>>>(env_ids, base, h->R, h->params, h->state, h->recs,
-                                                                                          sorted, h->cfg.noise_flags, h->tile_search));
+            if (h->tile_search) {
+                QD_DISPATCH_N(h->N, qd_k_candidates<NN, true><<<g1, dim3(QD_CAND_BLOCK), shm, s>>>(env_ids, base, h->R, h->params, h->state, h->recs,
+                                                                                                    sorted, h->cfg.noise_flags));
+            } else {
+                QD_DISPATCH_N(h->N, qd_k_candidates<NN, false><<<g1, dim3(QD_CAND_BLOCK), shm, s>>>(env_ids, base, h->R, h->params, h->state, h->recs,
+                                                                                                     sorted, h->cfg.noise_flags));
+            }
             QD_HIP(hipGetLastError());
         }
     }

@@ -168,11 +168,12 @@ __global__ void qd_k_telegraph(const int* __restrict__ env_ids, int n_env, int C
 #define QD_CAND_WAVES 2         // <= 256 VGPRs: 2 waves per SIMD, which is also what the 40 KB of LDS per block allows
 #endif
 
-template <int N>
+// REDO: second pass behind the tile search (only the pixels it flagged; their front end comes with the record)
+template <int N, bool REDO>
 __global__ void __launch_bounds__(QD_CAND_BLOCK, QD_CAND_WAVES)
 qd_k_candidates(const int* __restrict__ env_ids, int env_base, int R, const double* __restrict__ params,
-                const double* __restrict__ state, QdPixelRec* __restrict__ recs, int sort_output, int noise_flags,
-                int only_flagged) {
+                const double* __restrict__ state, QdPixelRec* __restrict__ recs, int sort_output, int noise_flags) {
+    constexpr int only_flagged = REDO ? 1 : 0;
     constexpr int G = N + 1, NB = N - 1, V = 2 * N;
     const QdLayout L = qd_layout(N);
     const int slot = blockIdx.z;
