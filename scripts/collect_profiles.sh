@@ -15,7 +15,7 @@ rocprofv3 --kernel-trace --stats -d $out/kstats --output-format csv -- python3 b
 cp $out/kstats/*/*kernel_stats.csv $out/kernel_stats_bench_headline.csv 2>/dev/null
 # PMC passes on ONE launch chunk of the bench (CHUNK envs, 8-dot 64x64) in the bench's regime: envs reset, then stepped with
 # uniform random actions for e % 12 + 1 steps (kbench mode wild12); the last dispatch of every kernel is the timed launch
-CHUNK=${CHUNK:-194}
+CHUNK=${CHUNK:-180}
 mkdir -p $out/pmc; i=0
 for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_ANY" \
            "SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_WAVE_CYCLES" \
