@@ -410,13 +410,14 @@ static int qd_launch_ground(qd_handle* h, const int32_t* env_ids, int base, int 
         const unsigned batches = (unsigned)((size_t)n * h->C * nb);
         if (stages & 1) {
         QD_HIP(hipMemsetAsync(h->gtiles, 0, sizeof(unsigned) * 16, s));
-        if (h->eig) {
-            QD_DISPATCH_N(h->N, qd_k_gs_structure<NN, true><<<dim3(batches), dim3(QD_GS_BLOCK), 0, s>>>(env_ids, base + off, rec0 + off, g, h->R,
-                          h->params, h->recs, h->state, h->cfg.noise_flags, h->slabs, h->gtiles, tilelist, h->gs_batches));
-        } else {
-            QD_DISPATCH_N(h->N, qd_k_gs_structure<NN, false><<<dim3(batches), dim3(QD_GS_BLOCK), 0, s>>>(env_ids, base + off, rec0 + off, g, h->R,
-                          h->params, h->recs, h->state, h->cfg.noise_flags, h->slabs, h->gtiles, tilelist, h->gs_batches));
-        }
+        // (small launches: 16 waves per batch instead of 4, see the kernel)
+#define QD_LAUNCH_STRUCTURE(VAL_, WPB_)                                                                                          \
+        QD_DISPATCH_N(h->N, qd_k_gs_structure<NN, VAL_, WPB_><<<dim3(batches), dim3(64 * WPB_), 0, s>>>(env_ids, base + off, rec0 + off, g, h->R, \
+                      h->params, h->recs, h->state, h->cfg.noise_flags, h->slabs, h->gtiles, tilelist, h->gs_batches))
+        const bool small = batches < (unsigned)h->cus;
+        if (h->eig) { if (small) { QD_LAUNCH_STRUCTURE(true, 16); } else { QD_LAUNCH_STRUCTURE(true, 4); } }
+        else        { if (small) { QD_LAUNCH_STRUCTURE(false, 16); } else { QD_LAUNCH_STRUCTURE(false, 4); } }
+#undef QD_LAUNCH_STRUCTURE
         QD_HIP(hipGetLastError());
         }
         if (stages & 2) {

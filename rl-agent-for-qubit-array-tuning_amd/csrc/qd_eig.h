@@ -104,10 +104,21 @@ QD_HD void qd_eig_lowest(const double* Ain, double& lam_out, double* x, double& 
     // sz <= S: a smaller block is PADDED to S rows with decoupled states (after the scaling: diagonal 4 > ||A||, zero
     // couplings), which the reflectors leave alone and whose eigenvalues lie to the right of every real one
     double a[NE];
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (sz == S) {
+        // task records are 16-byte aligned: pairs of doubles per load (half the address work of the per-lane strided loads)
+        const double2* A2 = reinterpret_cast<const double2*>(Ain);
 #pragma unroll
-    for (int i = 0; i < S; ++i)
+        for (int e = 0; e + 1 < NE; e += 2) { const double2 v = A2[e >> 1]; a[e] = v.x; a[e + 1] = v.y; }
+        if (NE & 1) a[NE - 1] = Ain[NE - 1];
+    } else
+#endif
+    {
 #pragma unroll
-        for (int j = 0; j <= i; ++j) a[QD_IX(i, j)] = (i < sz) ? Ain[QD_IX(i, j)] : 0.0;
+        for (int i = 0; i < S; ++i)
+#pragma unroll
+            for (int j = 0; j <= i; ++j) a[QD_IX(i, j)] = (i < sz) ? Ain[QD_IX(i, j)] : 0.0;
+    }
     // ---- 1. scale ----
     double anorm = 0.0;
 #pragma unroll

@@ -79,7 +79,8 @@ __host__ __device__ inline int qd_gs_list_cap(int bin) { return QD_GS_PPB * (32 
 __host__ __device__ inline int qd_gs_list_off(int bin) { int o = 0; for (int b = 0; b < bin; ++b) o += qd_gs_list_cap(b); return o; }
 __host__ __device__ inline int qd_gs_task_doubles(int s, bool validate) {
     const int ne = s * (s + 1) / 2;
-    return 2 + ne + (s > QD_EIG_REG ? 4 * s + (validate ? ne : 0) : 0);
+    const int n = 2 + ne + (s > QD_EIG_REG ? 4 * s + (validate ? ne : 0) : 0);
+    return (n + 1) & ~1;                                  // records stay 16-byte aligned: the solvers load / store pairs of doubles
 }
 // worst case per pixel: one component of all 32 states
 __host__ __device__ inline size_t qd_gs_pool_doubles(bool validate) { return (size_t)QD_GS_PPB * (size_t)qd_gs_task_doubles(32, validate); }
@@ -324,8 +325,15 @@ __device__ __forceinline__ int qd_eig_task(double* rec, double& lam) {
     const int sz = PADDED ? (int)rec[1] : S;
     qd_eig_lowest<S, VALIDATE>(rec + 2, lam, x, resid, VALIDATE ? &its : nullptr, sz);
     if (VALIDATE) rec[1] = resid;                          // (the eigenvalue goes to the slab's dense array: qd_k_gs_solve)
+    if (sz == S) {
+        double2* X2 = reinterpret_cast<double2*>(rec + 2);
 #pragma unroll
-    for (int i = 0; i < S; ++i) if (i < sz) rec[2 + i] = x[i];
+        for (int i = 0; i + 1 < S; i += 2) X2[i >> 1] = make_double2(x[i], x[i + 1]);
+        if (S & 1) rec[2 + S - 1] = x[S - 1];
+    } else {
+#pragma unroll
+        for (int i = 0; i < S; ++i) if (i < sz) rec[2 + i] = x[i];
+    }
     return its;
 }
 // Blocks of 13..32 states (0.1 % of the pixels have one): the same algorithm with run-time loops in the task's record -- a serial

@@ -271,14 +271,17 @@ __device__ __forceinline__ void qd_gs_locate(const QdGsGeom& g, int batch, int& 
                                  // bound (ds_bpermute / LDS chains): measured per env-step 4 waves per SIMD 26.8 us, 5: 22.6, 6: 20.5, 7: 19.6,
                                  // 8 (64 VGPRs, 116 B of scratch): 31.2
 #endif
-template <int N, bool VALIDATE>
-__global__ void __launch_bounds__(QD_GS_BLOCK, QD_GS_WAVES)
+// WPB waves per block: 4 in batch work; 16 for small launches (fewer batches than the chip has CUs: the launch takes as long as
+// ONE block, so the batch's 128 wave iterations are spread over 16 waves instead of 4 -- 2-dot 32x32, 1 env: 158 -> 45 us)
+template <int N, bool VALIDATE, int WPB>
+__global__ void __launch_bounds__(64 * WPB, WPB == 4 ? QD_GS_WAVES : 4)
 qd_k_gs_structure(const int* __restrict__ env_ids, int env_base, int rec_slot0, QdGsGeom g, int R, const double* __restrict__ params,
                   const QdPixelRec* __restrict__ recs, const double* __restrict__ state, int noise_flags,
                   unsigned char* __restrict__ slabs, unsigned* __restrict__ gtiles, unsigned* __restrict__ tilelist, size_t batches_cap) {
     const QdLayout L = qd_layout(N);
-    __shared__ QdWaveLds<N> sW[QD_GS_BLOCK / 64];
+    __shared__ QdWaveLds<N> sW[WPB];
     __shared__ QdBlockLds sB;
+    constexpr int PPW = QD_GS_PPB / WPB;                                  // pixels per wave
     const int batch = blockIdx.x;
     const QdSlab sl = qd_gs_slab(slabs + (size_t)batch * qd_gs_slab_bytes(VALIDATE), VALIDATE);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -295,9 +298,9 @@ qd_k_gs_structure(const int* __restrict__ env_ids, int env_base, int rec_slot0, 
     if (threadIdx.x <= QD_GS_NBIN) { if (threadIdx.x == 0) sB.pool_top = 0; else sB.cnt[threadIdx.x - 1] = 0; }
     __syncthreads();
     QdWaveLds<N>& W = sW[wave];
-    for (int it = 0; it < QD_GS_PPB / 8; ++it) {
-        const int ps = wave * (QD_GS_PPB / 4) + it * 2 + (lane >> 5);
-        if (p0 + wave * (QD_GS_PPB / 4) + it * 2 >= g.P) break;                 // uniform for the wave
+    for (int it = 0; it < PPW / 2; ++it) {
+        const int ps = wave * PPW + it * 2 + (lane >> 5);
+        if (p0 + wave * PPW + it * 2 >= g.P) break;                              // uniform for the wave
         const int p = p0 + ps;
         // both halves of a wave run in lock step: clamp instead of exiting
         const int pc = p < g.P ? p : g.P - 1;
@@ -563,17 +566,40 @@ __device__ unsigned long long qd_radix_select(const double* __restrict__ z, long
         for (int i = threadIdx.x; i < 256; i += blockDim.x) hist[i] = 0;
         __syncthreads();
         const int shift = pass * 8;
-        for (long i = threadIdx.x; i < n; i += blockDim.x) {
-            const unsigned long long k = qd_key(z[i]);
-            if ((k & mask) == prefix) atomicAdd(&hist[(k >> shift) & 255], 1u);
+        for (long i0 = 0; i0 < n; i0 += blockDim.x) {                       // (uniform trip count: the wave votes below)
+            const long i = i0 + threadIdx.x;
+            bool in = false; unsigned d = 0;
+            if (i < n) {
+                const unsigned long long k = qd_key(z[i]);
+                in = (k & mask) == prefix; d = (unsigned)(k >> shift) & 255u;
+            }
+            // the leading bytes of an image's values are mostly equal: one add per wave instead of 64 colliding LDS atomics
+            const unsigned long long act = __ballot(in);
+            if (act) {
+                const unsigned d0 = (unsigned)__builtin_amdgcn_readlane((int)d, __builtin_ctzll(act));
+                if (__ballot(in && d == d0) == act) {
+                    if ((int)(threadIdx.x & 63) == __builtin_ctzll(act)) atomicAdd(&hist[d0], (unsigned)__builtin_popcountll(act));
+                } else if (in) atomicAdd(&hist[d], 1u);
+            }
         }
         __syncthreads();
-        if (threadIdx.x == 0) {
-            long acc = 0; int b = 0;
-            for (; b < 256; ++b) { if (acc + (long)hist[b] > t) break; acc += hist[b]; }
-            if (b > 255) b = 255;
-            *sh_prefix = prefix | ((unsigned long long)b << shift);
-            *sh_t = t - acc;
+        if (threadIdx.x < 64) {
+            // first bin b with count(bins <= b) > t: 4 bins per lane, wave prefix sum
+            const int l = threadIdx.x;
+            const unsigned h4[4] = {hist[4 * l], hist[4 * l + 1], hist[4 * l + 2], hist[4 * l + 3]};
+            const long own = (long)h4[0] + (long)h4[1] + (long)h4[2] + (long)h4[3];
+            long inc = own;
+            for (int o = 1; o < 64; o <<= 1) { const long v = (long)__shfl_up((long long)inc, o, 64); if (l >= o) inc += v; }
+            const long exc = inc - own;
+            const unsigned long long hit = __ballot(inc > t);
+            const int wl = hit ? __builtin_ctzll(hit) : 63;
+            if (l == wl) {
+                long acc = exc; int b = 4 * l;
+                for (int j = 0; j < 4; ++j, ++b) { if (acc + (long)h4[j] > t) break; acc += h4[j]; }
+                if (b > 255) b = 255;
+                *sh_prefix = prefix | ((unsigned long long)b << shift);
+                *sh_t = t - acc;
+            }
         }
         __syncthreads();
         prefix = *sh_prefix; t = *sh_t;

@@ -28,7 +28,7 @@ def dur_of_pass(kernel_sub, counter):
     return d[0] if d else None
 CLOCK, SIMDS = 2.4e9, 1024
 pixels = envs * (N - 1) * R * R
-kern = {"qd_k_tile": f"qd_k_tile<{N}>", "qd_k_candidates": f"qd_k_candidates<{N}, true>", "qd_k_gs_structure": f"qd_k_gs_structure<{N}, false>",
+kern = {"qd_k_tile": f"qd_k_tile<{N}>", "qd_k_candidates": f"qd_k_candidates<{N}, true>", "qd_k_gs_structure": f"qd_k_gs_structure<{N}, false, 4>",
         "qd_k_gs_select": f"qd_k_gs_select<{N}, false>"}
 for b in range(10):
     kern[f"qd_k_gs_solve<{b}>"] = f"qd_k_gs_solve<{b}, false>"
