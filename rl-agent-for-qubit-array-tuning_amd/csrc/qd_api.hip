@@ -426,7 +426,7 @@ static int qd_launch_ground(qd_handle* h, const int32_t* env_ids, int base, int 
         // stream; large ones put the memory solver of the rare 13..32-state blocks (one long latency chain) and the wide register
         // solvers on two side streams.
         const int max_bin = h->N == 2 ? qd_gs_bin(4) : (h->N == 3 ? qd_gs_bin(12) : QD_GS_NBIN - 1);
-        const bool forked = batches >= 2048;
+        const bool forked = batches >= 2048 || (max_bin >= 9 && batches < (unsigned)h->cus);   // (a single image: every launch is one wave's latency)
         hipStream_t s9 = forked ? h->side : s, s48 = forked ? h->side2 : s;
         if (forked) {
             QD_HIP(hipEventRecord(h->ev_fork, s));
@@ -554,7 +554,10 @@ extern "C" int qd_observe(qd_handle* h, const int32_t* env_ids, int n, void* str
         QD_DISPATCH_N(h->N, qd_k_sensor<NN><<<g3, dim3(256), 0, s>>>(env_ids, h->R, h->params, h->state, h->zraw, qd_noise_cfg(h)));
         QD_HIP(hipGetLastError());
     }
-    qd_k_percentile<<<dim3(n), dim3(QD_PCT_BLOCK), 0, s>>>(env_ids, (long)h->C * h->P, h->zraw, h->plohi);
+    if ((long)h->C * h->P <= (long)QD_PCT_KPT * QD_PCT_BLOCK)
+        qd_k_percentile<true><<<dim3(n), dim3(QD_PCT_BLOCK), 0, s>>>(env_ids, (long)h->C * h->P, h->zraw, h->plohi);
+    else
+        qd_k_percentile<false><<<dim3(n), dim3(QD_PCT_BLOCK), 0, s>>>(env_ids, (long)h->C * h->P, h->zraw, h->plohi);
     QD_HIP(hipGetLastError());
     if (h->gimg || h->pimg || h->bimg || h->volt) {
         dim3 g4((h->P + 255) / 256, n);
@@ -574,7 +577,7 @@ extern "C" int qd_update_capacitance(qd_handle* h, const int32_t* env_ids, int n
     if (n == 0) return QD_OK;
     QdKalmanCfg kc{h->cfg.kalman_variance_threshold, h->cfg.kalman_process_noise, h->cfg.update_method == QD_UPDATE_DIRECT ? 1 : 0,
                    h->cfg.cnn_outputs};
-    const int blk = 64, grd = (n + blk - 1) / blk;
+    const int blk = QD_UPD_BLOCK, grd = (n + blk - 1) / blk;
     QD_DISPATCH_N(h->N, qd_k_update<NN><<<dim3(grd), dim3(blk), 0, s>>>(env_ids, n, h->params,
                                             h->state, values, log_vars, recompute_gt, kc));
     QD_HIP(hipGetLastError());

@@ -558,21 +558,43 @@ __device__ __forceinline__ double qd_unkey(unsigned long long k) {
     return __longlong_as_double((long long)u);
 }
 
+// The keys of one env, visited by the whole block in step (every thread calls f the same number of times, with `in` false
+// past the end, so f may vote across the wave).  CACHED: thread t keeps the keys of values t, t + 1024, ... in registers
+// (images of up to 32 768 values: the 16 histogram passes and the rank pass run without touching memory again).
+#define QD_PCT_KPT 32
+template <bool CACHED>
+struct QdPctKeys {
+    const double* z; long n;
+    unsigned long long keys[CACHED ? QD_PCT_KPT : 1];
+    template <class F>
+    __device__ __forceinline__ void each(F&& f) const {
+        if constexpr (CACHED) {
+#pragma unroll
+            for (int j = 0; j < QD_PCT_KPT; ++j) {
+                if ((long)j * QD_PCT_BLOCK >= n) break;
+                f((long)j * QD_PCT_BLOCK + threadIdx.x < n, keys[j]);
+            }
+        } else {
+            for (long i0 = 0; i0 < n; i0 += QD_PCT_BLOCK) {
+                const long i = i0 + threadIdx.x;
+                f(i < n, i < n ? qd_key(z[i]) : 0ull);
+            }
+        }
+    }
+};
+
 // value of rank `t` (0-based) among n keys
-__device__ unsigned long long qd_radix_select(const double* __restrict__ z, long n, long t, unsigned* hist /*256*/,
-                                              unsigned long long* sh_prefix, long* sh_t) {
+template <bool CACHED>
+__device__ __forceinline__ unsigned long long qd_radix_select(const QdPctKeys<CACHED>& K, long t, unsigned* hist /*256*/,
+                                                              unsigned long long* sh_prefix, long* sh_t) {
     unsigned long long prefix = 0, mask = 0;
     for (int pass = 7; pass >= 0; --pass) {
         for (int i = threadIdx.x; i < 256; i += blockDim.x) hist[i] = 0;
         __syncthreads();
         const int shift = pass * 8;
-        for (long i0 = 0; i0 < n; i0 += blockDim.x) {                       // (uniform trip count: the wave votes below)
-            const long i = i0 + threadIdx.x;
-            bool in = false; unsigned d = 0;
-            if (i < n) {
-                const unsigned long long k = qd_key(z[i]);
-                in = (k & mask) == prefix; d = (unsigned)(k >> shift) & 255u;
-            }
+        K.each([&](bool valid, unsigned long long k) {
+            const bool in = valid && (k & mask) == prefix;
+            const unsigned d = (unsigned)(k >> shift) & 255u;
             // the leading bytes of an image's values are mostly equal: one add per wave instead of 64 colliding LDS atomics
             const unsigned long long act = __ballot(in);
             if (act) {
@@ -581,7 +603,7 @@ __device__ unsigned long long qd_radix_select(const double* __restrict__ z, long
                     if ((int)(threadIdx.x & 63) == __builtin_ctzll(act)) atomicAdd(&hist[d0], (unsigned)__builtin_popcountll(act));
                 } else if (in) atomicAdd(&hist[d], 1u);
             }
-        }
+        });
         __syncthreads();
         if (threadIdx.x < 64) {
             // first bin b with count(bins <= b) > t: 4 bins per lane, wave prefix sum
@@ -616,10 +638,10 @@ __device__ __forceinline__ double qd_lerp(double a, double b, double t) {
     return r;
 }
 
+template <bool CACHED>
 __global__ void __launch_bounds__(QD_PCT_BLOCK)
 qd_k_percentile(const int* __restrict__ env_ids, long n, const double* __restrict__ zraw, double* __restrict__ plohi) {
     const int e = env_ids ? env_ids[blockIdx.x] : blockIdx.x;
-    const double* z = zraw + (size_t)e * n;
     __shared__ unsigned hist[256];
     __shared__ unsigned long long sh_prefix;
     __shared__ long sh_t;
@@ -627,8 +649,19 @@ qd_k_percentile(const int* __restrict__ env_ids, long n, const double* __restric
     __shared__ int sh_nan;
     if (threadIdx.x == 0) sh_nan = 0;
     __syncthreads();
+    QdPctKeys<CACHED> K;
+    K.z = zraw + (size_t)e * n; K.n = n;
     int has_nan = 0;
-    for (long i = threadIdx.x; i < n; i += blockDim.x) has_nan |= (z[i] != z[i]);
+    if constexpr (CACHED) {
+#pragma unroll
+        for (int j = 0; j < QD_PCT_KPT; ++j) {
+            K.keys[j] = 0ull;
+            const long i = (long)j * QD_PCT_BLOCK + threadIdx.x;
+            if (i < n) { const double v = K.z[i]; has_nan |= (v != v); K.keys[j] = qd_key(v); }
+        }
+    } else {
+        for (long i = threadIdx.x; i < n; i += blockDim.x) has_nan |= (K.z[i] != K.z[i]);
+    }
     if (has_nan) sh_nan = 1;
     __syncthreads();
     if (sh_nan) { if (threadIdx.x == 0) { plohi[2 * e] = NAN; plohi[2 * e + 1] = NAN; } return; }
@@ -640,16 +673,14 @@ qd_k_percentile(const int* __restrict__ env_ids, long n, const double* __restric
         long ip = (long)prev; if (ip < 0) ip = 0; if (ip > n - 1) ip = n - 1;
         long in = ip + 1; if (in > n - 1) in = n - 1;
         const double g = virt - prev;
-        const unsigned long long ka = qd_radix_select(z, n, ip, hist, &sh_prefix, &sh_t);
+        const unsigned long long ka = qd_radix_select<CACHED>(K, ip, hist, &sh_prefix, &sh_t);
         unsigned long long kb = ka;
         if (in != ip) {
             // rank ip+1: equal to ka if enough values <= ka, else the smallest key > ka
             long cnt_le = 0; unsigned long long mn = ~0ull;
-            for (long i = threadIdx.x; i < n; i += blockDim.x) {
-                const unsigned long long k = qd_key(z[i]);
-                cnt_le += k <= ka;
-                if (k > ka && k < mn) mn = k;
-            }
+            K.each([&](bool valid, unsigned long long k) {
+                if (valid) { cnt_le += k <= ka; if (k > ka && k < mn) mn = k; }
+            });
             // block reductions (sum of cnt_le, min of mn)
             for (int o = 32; o > 0; o >>= 1) {
                 cnt_le += __shfl_xor((long long)cnt_le, o, 64);
@@ -743,16 +774,20 @@ struct QdKalmanCfg { double variance_threshold, process_noise; int direct, n_out
 
 // pseudo-inverse of an n x n matrix (row-major, n <= 9) by one-sided Jacobi SVD,
 // numpy.linalg.pinv semantics: singular values <= 1e-15 * s_max are dropped.
-__device__ void qd_pinv(const double* M, int n, double* Pinv) {
-    double Um[81], Vm[81], sv[9];
-    for (int i = 0; i < n * n; ++i) { Um[i] = M[i]; Vm[i] = 0.0; }
-    for (int i = 0; i < n; ++i) Vm[i * n + i] = 1.0;
+// Um / Vm: the thread's two n x n work matrices, element i at [i * ST] (the kernel keeps them in LDS, one column of the
+// block's array per thread: the rotations index them at run time, which as private arrays meant scratch memory -- 8 dots,
+// one env: 490 -> 160 us for the update kernel)
+template <int ST>
+__device__ void qd_pinv(const double* M, int n, double* Pinv, double* Um, double* Vm) {
+    double sv[9];
+    for (int i = 0; i < n * n; ++i) { Um[i * ST] = M[i]; Vm[i * ST] = 0.0; }
+    for (int i = 0; i < n; ++i) Vm[(i * n + i) * ST] = 1.0;
     for (int sweep = 0; sweep < 60; ++sweep) {
         double offmax = 0.0;
         for (int p = 0; p < n - 1; ++p)
             for (int q = p + 1; q < n; ++q) {
                 double app = 0, aqq = 0, apq = 0;
-                for (int k = 0; k < n; ++k) { const double up = Um[k * n + p], uq = Um[k * n + q]; app += up * up; aqq += uq * uq; apq += up * uq; }
+                for (int k = 0; k < n; ++k) { const double up = Um[(k * n + p) * ST], uq = Um[(k * n + q) * ST]; app += up * up; aqq += uq * uq; apq += up * uq; }
                 if (apq == 0.0) continue;
                 const double rel = fabs(apq) / sqrt(app * aqq);
                 if (rel > offmax) offmax = rel;
@@ -761,10 +796,10 @@ __device__ void qd_pinv(const double* M, int n, double* Pinv) {
                 const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
                 const double cs = 1.0 / sqrt(1.0 + t * t), sn = cs * t;
                 for (int k = 0; k < n; ++k) {
-                    const double up = Um[k * n + p], uq = Um[k * n + q];
-                    Um[k * n + p] = cs * up - sn * uq; Um[k * n + q] = sn * up + cs * uq;
-                    const double vp = Vm[k * n + p], vq = Vm[k * n + q];
-                    Vm[k * n + p] = cs * vp - sn * vq; Vm[k * n + q] = sn * vp + cs * vq;
+                    const double up = Um[(k * n + p) * ST], uq = Um[(k * n + q) * ST];
+                    Um[(k * n + p) * ST] = cs * up - sn * uq; Um[(k * n + q) * ST] = sn * up + cs * uq;
+                    const double vp = Vm[(k * n + p) * ST], vq = Vm[(k * n + q) * ST];
+                    Vm[(k * n + p) * ST] = cs * vp - sn * vq; Vm[(k * n + q) * ST] = sn * vp + cs * vq;
                 }
             }
         if (!(offmax > 1e-15)) break;
@@ -772,7 +807,7 @@ __device__ void qd_pinv(const double* M, int n, double* Pinv) {
     double smax = 0.0;
     for (int j = 0; j < n; ++j) {
         double s = 0.0;
-        for (int k = 0; k < n; ++k) s += Um[k * n + j] * Um[k * n + j];
+        for (int k = 0; k < n; ++k) s += Um[(k * n + j) * ST] * Um[(k * n + j) * ST];
         sv[j] = sqrt(s);
         if (sv[j] > smax) smax = sv[j];
     }
@@ -782,7 +817,7 @@ __device__ void qd_pinv(const double* M, int n, double* Pinv) {
         for (int k = 0; k < n; ++k) {
             double acc = 0.0;
             for (int j = 0; j < n; ++j)
-                if (sv[j] > cutoff) acc += Vm[i * n + j] * Um[k * n + j] / (sv[j] * sv[j]);
+                if (sv[j] > cutoff) acc += Vm[(i * n + j) * ST] * Um[(k * n + j) * ST] / (sv[j] * sv[j]);
             Pinv[i * n + k] = acc;
         }
 }
@@ -833,11 +868,14 @@ __device__ bool qd_kalman_update(double* mean, double* var, int i, int j, double
     return true;
 }
 
+#define QD_UPD_BLOCK 64
 template <int N>
-__global__ void qd_k_update(const int* __restrict__ env_ids, int n_env, const double* __restrict__ params,
+__global__ void __launch_bounds__(QD_UPD_BLOCK)
+qd_k_update(const int* __restrict__ env_ids, int n_env, const double* __restrict__ params,
                             double* __restrict__ state, const float* __restrict__ values,
                             const float* __restrict__ log_vars, int recompute_gt, QdKalmanCfg kc) {
     constexpr int G = N + 1, C = N - 1;
+    __shared__ double sU[G * G * QD_UPD_BLOCK], sV[G * G * QD_UPD_BLOCK];      // qd_pinv's work matrices, [element][thread]
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_env) return;
     const int e = env_ids ? env_ids[t] : t;
@@ -880,7 +918,7 @@ __global__ void qd_k_update(const int* __restrict__ env_ids, int n_env, const do
                 }
                 M[i * G + j] = acc;
             }
-        qd_pinv(M, G, Pv);
+        qd_pinv<QD_UPD_BLOCK>(M, G, Pv, sU + threadIdx.x, sV + threadIdx.x);
         for (int i = 0; i < G * G; ++i) st[L.s_vgm + i] = Pv[i];
     }
     if (recompute_gt) {

@@ -514,6 +514,25 @@ def test_dataset_generator_format_and_values(tmp_path):
     gen.close()
 
 
+@pytest.mark.parametrize("N,R,B", [(2, 32, 3), (4, 64, 2), (4, 128, 2), (3, 200, 1)])
+def test_percentiles_are_numpy_exact_on_both_kernel_paths(N, R, B):
+    """qd_k_percentile keeps an image's keys in registers when it has at most 32 768 values and re-reads them from
+    memory otherwise (4 dots at 128x128: 49 152 values; 3 dots at 200x200: 80 000, not a multiple of the block): both
+    must reproduce numpy's linear-interpolation percentiles of the GPU's own raw signal bit for bit, after a reset and
+    after random steps (ties and equal leading key bytes occur in flat images)."""
+    import torch
+    env = _env(B, N, R)
+    env.reset()
+    gen = torch.Generator(device="cpu").manual_seed(3)
+    for step in range(3):
+        raw, plohi = env.raw()
+        assert np.isfinite(raw).all()
+        for e in range(B):
+            assert plohi[e, 0] == np.percentile(raw[e], 0.5) and plohi[e, 1] == np.percentile(raw[e], 99.5), (N, R, e, step)
+        env.step((torch.rand((B, 2 * N - 1), generator=gen) * 2 - 1).cuda())
+    env.close()
+
+
 def test_nan_inputs_give_zero_image_not_a_hang():
     """env.py:499-506: if the percentiles are not ordered (NaN data) the normalised image is all
     zeros.  A poisoned parameter block must neither hang nor fault the kernels, and must not
