@@ -577,7 +577,7 @@ extern "C" int qd_update_capacitance(qd_handle* h, const int32_t* env_ids, int n
     if (n == 0) return QD_OK;
     QdKalmanCfg kc{h->cfg.kalman_variance_threshold, h->cfg.kalman_process_noise, h->cfg.update_method == QD_UPDATE_DIRECT ? 1 : 0,
                    h->cfg.cnn_outputs};
-    const int blk = QD_UPD_BLOCK, grd = (n + blk - 1) / blk;
+    const int blk = QD_UPD_BLOCK, grd = n;                           // one wave per env
     QD_DISPATCH_N(h->N, qd_k_update<NN><<<dim3(grd), dim3(blk), 0, s>>>(env_ids, n, h->params,
                                             h->state, values, log_vars, recompute_gt, kc));
     QD_HIP(hipGetLastError());

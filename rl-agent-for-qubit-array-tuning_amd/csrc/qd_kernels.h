@@ -583,52 +583,58 @@ struct QdPctKeys {
     }
 };
 
-// value of rank `t` (0-based) among n keys
+// values of the ranks t[0], t[1] (0-based) among n keys, both selections in the same eight passes
 template <bool CACHED>
-__device__ __forceinline__ unsigned long long qd_radix_select(const QdPctKeys<CACHED>& K, long t, unsigned* hist /*256*/,
-                                                              unsigned long long* sh_prefix, long* sh_t) {
-    unsigned long long prefix = 0, mask = 0;
+__device__ __forceinline__ void qd_radix_select2(const QdPctKeys<CACHED>& K, long t0, long t1, unsigned (*hist)[256],
+                                                 unsigned long long* sh_prefix /*2*/, long* sh_t /*2*/, unsigned long long* out /*2*/) {
+    unsigned long long prefix[2] = {0, 0}, mask = 0;
+    long t[2] = {t0, t1};
     for (int pass = 7; pass >= 0; --pass) {
-        for (int i = threadIdx.x; i < 256; i += blockDim.x) hist[i] = 0;
+        for (int i = threadIdx.x; i < 512; i += blockDim.x) hist[i >> 8][i & 255] = 0;
         __syncthreads();
         const int shift = pass * 8;
         K.each([&](bool valid, unsigned long long k) {
-            const bool in = valid && (k & mask) == prefix;
             const unsigned d = (unsigned)(k >> shift) & 255u;
-            // the leading bytes of an image's values are mostly equal: one add per wave instead of 64 colliding LDS atomics
-            const unsigned long long act = __ballot(in);
-            if (act) {
-                const unsigned d0 = (unsigned)__builtin_amdgcn_readlane((int)d, __builtin_ctzll(act));
-                if (__ballot(in && d == d0) == act) {
-                    if ((int)(threadIdx.x & 63) == __builtin_ctzll(act)) atomicAdd(&hist[d0], (unsigned)__builtin_popcountll(act));
-                } else if (in) atomicAdd(&hist[d], 1u);
+#pragma unroll
+            for (int w = 0; w < 2; ++w) {
+                const bool in = valid && (k & mask) == prefix[w];
+                // the leading bytes of an image's values are mostly equal: one add per wave instead of 64 colliding LDS atomics
+                const unsigned long long act = __ballot(in);
+                if (act) {
+                    const unsigned d0 = (unsigned)__builtin_amdgcn_readlane((int)d, __builtin_ctzll(act));
+                    if (__ballot(in && d == d0) == act) {
+                        if ((int)(threadIdx.x & 63) == __builtin_ctzll(act)) atomicAdd(&hist[w][d0], (unsigned)__builtin_popcountll(act));
+                    } else if (in) atomicAdd(&hist[w][d], 1u);
+                }
             }
         });
         __syncthreads();
-        if (threadIdx.x < 64) {
-            // first bin b with count(bins <= b) > t: 4 bins per lane, wave prefix sum
-            const int l = threadIdx.x;
-            const unsigned h4[4] = {hist[4 * l], hist[4 * l + 1], hist[4 * l + 2], hist[4 * l + 3]};
+        if (threadIdx.x < 128) {
+            // first bin b with count(bins <= b) > t: wave w scans histogram w, 4 bins per lane, wave prefix sum
+            const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+            const long tw = w ? t[1] : t[0];
+            const unsigned long long pw = w ? prefix[1] : prefix[0];
+            const unsigned h4[4] = {hist[w][4 * l], hist[w][4 * l + 1], hist[w][4 * l + 2], hist[w][4 * l + 3]};
             const long own = (long)h4[0] + (long)h4[1] + (long)h4[2] + (long)h4[3];
             long inc = own;
             for (int o = 1; o < 64; o <<= 1) { const long v = (long)__shfl_up((long long)inc, o, 64); if (l >= o) inc += v; }
             const long exc = inc - own;
-            const unsigned long long hit = __ballot(inc > t);
+            const unsigned long long hit = __ballot(inc > tw);
             const int wl = hit ? __builtin_ctzll(hit) : 63;
             if (l == wl) {
                 long acc = exc; int b = 4 * l;
-                for (int j = 0; j < 4; ++j, ++b) { if (acc + (long)h4[j] > t) break; acc += h4[j]; }
+                for (int j = 0; j < 4; ++j, ++b) { if (acc + (long)h4[j] > tw) break; acc += h4[j]; }
                 if (b > 255) b = 255;
-                *sh_prefix = prefix | ((unsigned long long)b << shift);
-                *sh_t = t - acc;
+                sh_prefix[w] = pw | ((unsigned long long)b << shift);
+                sh_t[w] = tw - acc;
             }
         }
         __syncthreads();
-        prefix = *sh_prefix; t = *sh_t;
+        prefix[0] = sh_prefix[0]; prefix[1] = sh_prefix[1]; t[0] = sh_t[0]; t[1] = sh_t[1];
         mask |= 0xffull << shift;
         __syncthreads();
     }
-    return prefix;
+    out[0] = prefix[0]; out[1] = prefix[1];
 }
 
 __device__ __forceinline__ double qd_lerp(double a, double b, double t) {
@@ -642,10 +648,10 @@ template <bool CACHED>
 __global__ void __launch_bounds__(QD_PCT_BLOCK)
 qd_k_percentile(const int* __restrict__ env_ids, long n, const double* __restrict__ zraw, double* __restrict__ plohi) {
     const int e = env_ids ? env_ids[blockIdx.x] : blockIdx.x;
-    __shared__ unsigned hist[256];
-    __shared__ unsigned long long sh_prefix;
-    __shared__ long sh_t;
-    __shared__ unsigned long long sh_red[QD_PCT_BLOCK / 64];
+    __shared__ unsigned hist[2][256];
+    __shared__ unsigned long long sh_prefix[2];
+    __shared__ long sh_t[2];
+    __shared__ unsigned long long sh_red[4][QD_PCT_BLOCK / 64];
     __shared__ int sh_nan;
     if (threadIdx.x == 0) sh_nan = 0;
     __syncthreads();
@@ -665,44 +671,48 @@ qd_k_percentile(const int* __restrict__ env_ids, long n, const double* __restric
     if (has_nan) sh_nan = 1;
     __syncthreads();
     if (sh_nan) { if (threadIdx.x == 0) { plohi[2 * e] = NAN; plohi[2 * e + 1] = NAN; } return; }
-    double res[2];
+    long ip[2], in[2]; double g[2];
+#pragma unroll
     for (int which = 0; which < 2; ++which) {
         const double q = (which == 0 ? 0.5 : 99.5) / 100.0;
         const double virt = (double)(n - 1) * q;             // numpy 'linear' method: (n-1)*quantile
         const double prev = floor(virt);
-        long ip = (long)prev; if (ip < 0) ip = 0; if (ip > n - 1) ip = n - 1;
-        long in = ip + 1; if (in > n - 1) in = n - 1;
-        const double g = virt - prev;
-        const unsigned long long ka = qd_radix_select<CACHED>(K, ip, hist, &sh_prefix, &sh_t);
-        unsigned long long kb = ka;
-        if (in != ip) {
-            // rank ip+1: equal to ka if enough values <= ka, else the smallest key > ka
-            long cnt_le = 0; unsigned long long mn = ~0ull;
-            K.each([&](bool valid, unsigned long long k) {
-                if (valid) { cnt_le += k <= ka; if (k > ka && k < mn) mn = k; }
-            });
-            // block reductions (sum of cnt_le, min of mn)
-            for (int o = 32; o > 0; o >>= 1) {
-                cnt_le += __shfl_xor((long long)cnt_le, o, 64);
-                const unsigned long long other = (unsigned long long)__shfl_xor((long long)mn, o, 64);
-                mn = other < mn ? other : mn;
-            }
-            __syncthreads();
-            if ((threadIdx.x & 63) == 0) sh_red[threadIdx.x >> 6] = (unsigned long long)cnt_le;
-            __syncthreads();
-            long tot = 0;
-            for (int w = 0; w < QD_PCT_BLOCK / 64; ++w) tot += (long)sh_red[w];
-            __syncthreads();
-            if ((threadIdx.x & 63) == 0) sh_red[threadIdx.x >> 6] = mn;
-            __syncthreads();
-            unsigned long long gm = ~0ull;
-            for (int w = 0; w < QD_PCT_BLOCK / 64; ++w) gm = sh_red[w] < gm ? sh_red[w] : gm;
-            __syncthreads();
-            kb = (tot > in) ? ka : gm;
-        }
-        res[which] = qd_lerp(qd_unkey(ka), qd_unkey(kb), g);
+        ip[which] = (long)prev; if (ip[which] < 0) ip[which] = 0; if (ip[which] > n - 1) ip[which] = n - 1;
+        in[which] = ip[which] + 1; if (in[which] > n - 1) in[which] = n - 1;
+        g[which] = virt - prev;
     }
-    if (threadIdx.x == 0) { plohi[2 * e] = res[0]; plohi[2 * e + 1] = res[1]; }
+    unsigned long long ka[2];
+    qd_radix_select2<CACHED>(K, ip[0], ip[1], hist, sh_prefix, sh_t, ka);
+    // rank ip+1: equal to ka if enough values <= ka, else the smallest key > ka
+    long cnt_le[2] = {0, 0}; unsigned long long mn[2] = {~0ull, ~0ull};
+    K.each([&](bool valid, unsigned long long k) {
+        if (valid) {
+#pragma unroll
+            for (int w = 0; w < 2; ++w) { cnt_le[w] += k <= ka[w]; if (k > ka[w] && k < mn[w]) mn[w] = k; }
+        }
+    });
+    // block reductions (sums of cnt_le, minima of mn)
+#pragma unroll
+    for (int w = 0; w < 2; ++w)
+        for (int o = 32; o > 0; o >>= 1) {
+            cnt_le[w] += __shfl_xor((long long)cnt_le[w], o, 64);
+            const unsigned long long other = (unsigned long long)__shfl_xor((long long)mn[w], o, 64);
+            mn[w] = other < mn[w] ? other : mn[w];
+        }
+    if ((threadIdx.x & 63) == 0) {
+        sh_red[0][threadIdx.x >> 6] = (unsigned long long)cnt_le[0]; sh_red[1][threadIdx.x >> 6] = (unsigned long long)cnt_le[1];
+        sh_red[2][threadIdx.x >> 6] = mn[0]; sh_red[3][threadIdx.x >> 6] = mn[1];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 0; w < 2; ++w) {
+            long tot = 0; unsigned long long gm = ~0ull;
+            for (int v = 0; v < QD_PCT_BLOCK / 64; ++v) { tot += (long)sh_red[w][v]; gm = sh_red[2 + w][v] < gm ? sh_red[2 + w][v] : gm; }
+            unsigned long long kb = ka[w];
+            if (in[w] != ip[w]) kb = (tot > in[w]) ? ka[w] : gm;
+            plohi[2 * e + w] = qd_lerp(qd_unkey(ka[w]), qd_unkey(kb), g[w]);
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -772,59 +782,78 @@ __global__ void qd_k_write_obs(const int* __restrict__ env_ids, int R, const dou
 // ---------------------------------------------------------------------------
 struct QdKalmanCfg { double variance_threshold, process_noise; int direct, n_out; };
 
-// pseudo-inverse of an n x n matrix (row-major, n <= 9) by one-sided Jacobi SVD,
-// numpy.linalg.pinv semantics: singular values <= 1e-15 * s_max are dropped.
-// Um / Vm: the thread's two n x n work matrices, element i at [i * ST] (the kernel keeps them in LDS, one column of the
-// block's array per thread: the rotations index them at run time, which as private arrays meant scratch memory -- 8 dots,
-// one env: 490 -> 160 us for the update kernel)
-template <int ST>
-__device__ void qd_pinv(const double* M, int n, double* Pinv, double* Um, double* Vm) {
-    double sv[9];
-    for (int i = 0; i < n * n; ++i) { Um[i * ST] = M[i]; Vm[i * ST] = 0.0; }
-    for (int i = 0; i < n; ++i) Vm[(i * n + i) * ST] = 1.0;
+// pseudo-inverse of an n x n matrix (row-major, n <= 9) by one-sided Jacobi SVD, numpy.linalg.pinv semantics: singular
+// values <= 1e-15 * s_max are dropped.  ONE WAVE per matrix, everything in LDS (M, U, V, P: n*n doubles each, sv: n):
+// a sweep is n - 1 (n even) or n rounds of a round-robin schedule, each round rotating up to n / 2 DISJOINT column pairs
+// side by side (slot = lane / 12 owns a pair, its lane k < n owns row k of U and V and forms the pair's three column sums
+// itself, in row order) -- the serial chain of a sweep is 9 rotations instead of 36 for n = 9.  (One thread per env took
+// 490 us per call whatever the batch: ~290 rotations of 3 square roots and 4 divisions each.)
+template <int n>
+__device__ void qd_pinv_wave(const double* M, double* U, double* V, double* P, double* sv, int lane) {
+    constexpr int m = (n + 1) & ~1;                     // players of the schedule (one dummy when n is odd)
+    constexpr int SLOTW = 12;
+    static_assert(n <= 9 && (m / 2) * SLOTW <= 64, "pair slots must fit one wave");
+    for (int i = lane; i < n * n; i += 64) { U[i] = M[i]; V[i] = ((i / n) == (i % n)) ? 1.0 : 0.0; }
+    __builtin_amdgcn_wave_barrier();
+    const int slot = lane / SLOTW, k = lane - slot * SLOTW;
     for (int sweep = 0; sweep < 60; ++sweep) {
         double offmax = 0.0;
-        for (int p = 0; p < n - 1; ++p)
-            for (int q = p + 1; q < n; ++q) {
+        for (int r = 0; r < m - 1; ++r) {
+            int a, b;
+            if (slot == 0) { a = m - 1; b = r; }
+            else { a = (r + slot) % (m - 1); b = (r - slot + (m - 1)) % (m - 1); }
+            const bool mine = slot < m / 2 && a < n && b < n && k < n;
+            const int p = a < b ? a : b, q = a < b ? b : a;
+            bool rot = false;
+            double nup = 0, nuq = 0, nvp = 0, nvq = 0;
+            if (mine) {
                 double app = 0, aqq = 0, apq = 0;
-                for (int k = 0; k < n; ++k) { const double up = Um[(k * n + p) * ST], uq = Um[(k * n + q) * ST]; app += up * up; aqq += uq * uq; apq += up * uq; }
-                if (apq == 0.0) continue;
-                const double rel = fabs(apq) / sqrt(app * aqq);
-                if (rel > offmax) offmax = rel;
-                if (!(rel > 1e-16)) continue;
-                const double zeta = (aqq - app) / (2.0 * apq);
-                const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-                const double cs = 1.0 / sqrt(1.0 + t * t), sn = cs * t;
-                for (int k = 0; k < n; ++k) {
-                    const double up = Um[(k * n + p) * ST], uq = Um[(k * n + q) * ST];
-                    Um[(k * n + p) * ST] = cs * up - sn * uq; Um[(k * n + q) * ST] = sn * up + cs * uq;
-                    const double vp = Vm[(k * n + p) * ST], vq = Vm[(k * n + q) * ST];
-                    Vm[(k * n + p) * ST] = cs * vp - sn * vq; Vm[(k * n + q) * ST] = sn * vp + cs * vq;
+                for (int kk = 0; kk < n; ++kk) { const double up = U[kk * n + p], uq = U[kk * n + q]; app += up * up; aqq += uq * uq; apq += up * uq; }
+                if (apq != 0.0) {
+                    const double rel = fabs(apq) / sqrt(app * aqq);
+                    if (rel > offmax) offmax = rel;
+                    if (rel > 1e-16) {
+                        const double zeta = (aqq - app) / (2.0 * apq);
+                        const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                        const double cs = 1.0 / sqrt(1.0 + t * t), sn = cs * t;
+                        const double up = U[k * n + p], uq = U[k * n + q];
+                        nup = cs * up - sn * uq; nuq = sn * up + cs * uq;
+                        const double vp = V[k * n + p], vq = V[k * n + q];
+                        nvp = cs * vp - sn * vq; nvq = sn * vp + cs * vq;
+                        rot = true;
+                    }
                 }
             }
+            __builtin_amdgcn_wave_barrier();                 // every column sum of the round is formed before a column changes
+            if (rot) { U[k * n + p] = nup; U[k * n + q] = nuq; V[k * n + p] = nvp; V[k * n + q] = nvq; }
+            __builtin_amdgcn_wave_barrier();
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) offmax = fmax(offmax, __shfl_xor(offmax, o, 64));
         if (!(offmax > 1e-15)) break;
     }
-    double smax = 0.0;
-    for (int j = 0; j < n; ++j) {
+    if (lane < n) {
         double s = 0.0;
-        for (int k = 0; k < n; ++k) s += Um[(k * n + j) * ST] * Um[(k * n + j) * ST];
-        sv[j] = sqrt(s);
-        if (sv[j] > smax) smax = sv[j];
+        for (int kk = 0; kk < n; ++kk) s += U[kk * n + lane] * U[kk * n + lane];
+        sv[lane] = sqrt(s);
     }
+    __builtin_amdgcn_wave_barrier();
+    double smax = 0.0;
+    for (int j = 0; j < n; ++j) if (sv[j] > smax) smax = sv[j];
     const double cutoff = 1e-15 * smax;
     // M = U S V^T with U = Um / sv  =>  pinv = V S^-1 U^T = sum_j V[:,j] Um[:,j]^T / sv_j^2
-    for (int i = 0; i < n; ++i)
-        for (int k = 0; k < n; ++k) {
-            double acc = 0.0;
-            for (int j = 0; j < n; ++j)
-                if (sv[j] > cutoff) acc += Vm[(i * n + j) * ST] * Um[(k * n + j) * ST] / (sv[j] * sv[j]);
-            Pinv[i * n + k] = acc;
-        }
+    for (int idx = lane; idx < n * n; idx += 64) {
+        const int i = idx / n, kk = idx - i * n;
+        double acc = 0.0;
+        for (int j = 0; j < n; ++j)
+            if (sv[j] > cutoff) acc += V[i * n + j] * U[kk * n + j] / (sv[j] * sv[j]);
+        P[idx] = acc;
+    }
+    __builtin_amdgcn_wave_barrier();
 }
 
-// solve A x = b (n <= 9), Gaussian elimination with partial pivoting
-__device__ void qd_solve(const double* A, const double* b, int n, double* x) {
-    double M[81], r[9];
+// solve A x = b (n <= 9), Gaussian elimination with partial pivoting; M (n*n) and r (n): the caller's work space
+__device__ void qd_solve(const double* A, const double* b, int n, double* x, double* M, double* r) {
     for (int i = 0; i < n * n; ++i) M[i] = A[i];
     for (int i = 0; i < n; ++i) r[i] = b[i];
     for (int c = 0; c < n; ++c) {
@@ -868,6 +897,8 @@ __device__ bool qd_kalman_update(double* mean, double* var, int i, int j, double
     return true;
 }
 
+// one WAVE per env (block = 64): Kalman updates by lane 0 on an LDS copy of the estimate, the VGM product and its
+// pseudo-inverse by the wave, the ground truth (a 9 x 9 solve) by lane 0
 #define QD_UPD_BLOCK 64
 template <int N>
 __global__ void __launch_bounds__(QD_UPD_BLOCK)
@@ -875,8 +906,8 @@ qd_k_update(const int* __restrict__ env_ids, int n_env, const double* __restrict
                             double* __restrict__ state, const float* __restrict__ values,
                             const float* __restrict__ log_vars, int recompute_gt, QdKalmanCfg kc) {
     constexpr int G = N + 1, C = N - 1;
-    __shared__ double sU[G * G * QD_UPD_BLOCK], sV[G * G * QD_UPD_BLOCK];      // qd_pinv's work matrices, [element][thread]
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ double sMean[N * N], sVar[N * N], sM[G * G], sU[G * G], sV[G * G], sP[G * G], sSv[G], sX[G];
+    const int t = blockIdx.x, lane = threadIdx.x;
     if (t >= n_env) return;
     const int e = env_ids ? env_ids[t] : t;
     const QdLayout L = qd_layout(N);
@@ -885,50 +916,59 @@ qd_k_update(const int* __restrict__ env_ids, int n_env, const double* __restrict
     double* mean = st + L.s_kmean;
     double* var = st + L.s_kvar;
     if (values && log_vars) {
-        const int K = kc.n_out;                                   // 3, or 2 in the legacy nearest-neighbour mode
-        for (int i = 0; i < C; ++i) {
-            const float* vv = values + ((size_t)e * C + i) * K;
-            const float* lv = log_vars + ((size_t)e * C + i) * K;
-            // env.py:592-618: predictions negated; KalmanUpdater.py:87-90 clamp then exp
-            double Rv[3], dl[3];
-            for (int k = 0; k < K; ++k) {
-                dl[k] = -(double)vv[k];
-                const double c = fmin(fmax((double)lv[k], -6.0), 2.0);
-                Rv[k] = exp(c);
-            }
-            if (K == 2) {                                         // KalmanUpdater.py:183-205: [RL, LR], both land on (i, i+1)
-                qd_kalman_update<N>(mean, var, i + 1, i, dl[0], Rv[0], kc);
-                qd_kalman_update<N>(mean, var, i, i + 1, dl[1], Rv[1], kc);
-            } else {
-                qd_kalman_update<N>(mean, var, i, i + 1, dl[0], Rv[0], kc);
-                if (i + 2 < N) qd_kalman_update<N>(mean, var, i, i + 2, dl[1], Rv[1], kc);
-                if (i - 1 >= 0) qd_kalman_update<N>(mean, var, i + 1, i - 1, dl[2], Rv[2], kc);
+        for (int i = lane; i < N * N; i += 64) { sMean[i] = mean[i]; sVar[i] = var[i]; }
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) {
+            const int K = kc.n_out;                                   // 3, or 2 in the legacy nearest-neighbour mode
+            for (int i = 0; i < C; ++i) {
+                const float* vv = values + ((size_t)e * C + i) * K;
+                const float* lv = log_vars + ((size_t)e * C + i) * K;
+                // env.py:592-618: predictions negated; KalmanUpdater.py:87-90 clamp then exp
+                double Rv[3], dl[3];
+                for (int k = 0; k < K; ++k) {
+                    dl[k] = -(double)vv[k];
+                    const double c = fmin(fmax((double)lv[k], -6.0), 2.0);
+                    Rv[k] = exp(c);
+                }
+                if (K == 2) {                                         // KalmanUpdater.py:183-205: [RL, LR], both land on (i, i+1)
+                    qd_kalman_update<N>(sMean, sVar, i + 1, i, dl[0], Rv[0], kc);
+                    qd_kalman_update<N>(sMean, sVar, i, i + 1, dl[1], Rv[1], kc);
+                } else {
+                    qd_kalman_update<N>(sMean, sVar, i, i + 1, dl[0], Rv[0], kc);
+                    if (i + 2 < N) qd_kalman_update<N>(sMean, sVar, i, i + 2, dl[1], Rv[1], kc);
+                    if (i - 1 >= 0) qd_kalman_update<N>(sMean, sVar, i + 1, i - 1, dl[2], Rv[2], kc);
+                }
             }
         }
+        __builtin_amdgcn_wave_barrier();
+        for (int i = lane; i < N * N; i += 64) { mean[i] = sMean[i]; var[i] = sVar[i]; }
         // a20: VGM = pinv(cdd_inv_full @ (-E)), E = [[cgd_est, 0], [0, 1]]  (electrons sign folded in)
-        double M[G * G], Pv[G * G];
-        for (int i = 0; i < G; ++i)
-            for (int j = 0; j < G; ++j) {
-                double acc = 0.0;
-                for (int k = 0; k < G; ++k) {
-                    double ekj;
-                    if (k < N && j < N) ekj = (k == j) ? 1.0 : mean[k * N + j];
-                    else ekj = (k == N && j == N) ? 1.0 : 0.0;
-                    acc += par[L.cdd_inv + i * G + k] * (-ekj);
-                }
-                M[i * G + j] = acc;
+        for (int idx = lane; idx < G * G; idx += 64) {
+            const int i = idx / G, j = idx - i * G;
+            double acc = 0.0;
+            for (int k = 0; k < G; ++k) {
+                double ekj;
+                if (k < N && j < N) ekj = (k == j) ? 1.0 : sMean[k * N + j];
+                else ekj = (k == N && j == N) ? 1.0 : 0.0;
+                acc += par[L.cdd_inv + i * G + k] * (-ekj);
             }
-        qd_pinv<QD_UPD_BLOCK>(M, G, Pv, sU + threadIdx.x, sV + threadIdx.x);
-        for (int i = 0; i < G * G; ++i) st[L.s_vgm + i] = Pv[i];
+            sM[idx] = acc;
+        }
+        __builtin_amdgcn_wave_barrier();
+        qd_pinv_wave<G>(sM, sU, sV, sP, sSv, lane);
+        for (int idx = lane; idx < G * G; idx += 64) st[L.s_vgm + idx] = sP[idx];
+    } else if (recompute_gt) {
+        for (int idx = lane; idx < G * G; idx += 64) sP[idx] = st[L.s_vgm + idx];
+        __builtin_amdgcn_wave_barrier();
     }
-    if (recompute_gt) {
+    if (recompute_gt && lane == 0) {
         // a21: virtual = inv(VGM) (vopt - origin)
-        double rhs[G], virt[G];
+        double rhs[G];
         for (int i = 0; i < G; ++i) rhs[i] = par[L.vopt + i] - par[L.origin + i];
-        qd_solve(st + L.s_vgm, rhs, G, virt);
-        for (int i = 0; i < N; ++i) st[L.s_gate_gt + i] = (double)(float)virt[i];
+        qd_solve(sP, rhs, G, sX, sU, sSv);                            // (work space: the pseudo-inverse is done with sU / sSv)
+        for (int i = 0; i < N; ++i) st[L.s_gate_gt + i] = (double)(float)sX[i];
         for (int b = 0; b < C; ++b) st[L.s_barrier_gt + b] = (double)(float)par[L.vbopt + b];
-        st[L.s_sensor_gt] = virt[N];
+        st[L.s_sensor_gt] = sX[N];
     }
 }
 
