@@ -14,7 +14,7 @@ ap.add_argument("--iters", type=int, default=3); ap.add_argument("--pixel-search
 ap.add_argument("--each", action="store_true", help="also time every hot kernel by itself")
 a = ap.parse_args()
 env = VecQuantumDeviceEnv(a.envs, num_dots=a.dots, resolution=a.resolution, seed=1234, capacitance_model=SyntheticCapacitanceModel(1),
-                          pixel_search=a.pixel_search)
+                          pixel_search=a.pixel_search, env_chunk=a.envs)        # all envs in ONE launch (no split over the lanes)
 env.reset()
 st0, steps = env.get_state()
 rng = np.random.default_rng(0)
