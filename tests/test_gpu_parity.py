@@ -594,6 +594,36 @@ def test_chunked_launches_are_bit_identical_to_one_launch(N, R, B, chunk):
         env.close()
 
 
+def test_batch_split_over_the_two_lanes_is_bit_identical_to_one_launch():
+    """Without an explicit `env_chunk` a batch that fits one launch is cut in two halves for the two launch lanes when a
+    half still fills the GPU (>= 2 048 batches of 256 pixels: 48 8-dot 64x64 envs -> 2 x 24; 16 envs stay one launch).
+    Same bits as the single launch, through steps with auto-reset and a partial reset."""
+    import torch
+    from qadapt_hip.vec_env import VecQuantumDeviceEnv, SyntheticCapacitanceModel
+    N, R, B = 8, 64, 48
+    mk = lambda b, **kw: VecQuantumDeviceEnv(b, num_dots=N, resolution=R, seed=17, capacitance_model=SyntheticCapacitanceModel(7), **kw)
+    small = mk(16)
+    assert small.chunk_envs() == 16
+    small.close()
+    one = mk(B, env_chunk=B); split = mk(B)
+    assert one.chunk_envs() == B and split.chunk_envs() == B // 2
+    envs = (one, split)
+    for env in envs:
+        env.reset(); env.stagger_episodes()
+    gen = torch.Generator(device="cpu").manual_seed(8)
+    for step in range(4):
+        act = (torch.rand((B, 2 * N - 1), generator=gen) * 2 - 1).cuda()
+        outs = []
+        for env in envs:
+            obs, rew, term, trunc = env.step(act, auto_reset=True)[:4]
+            outs.append((obs["image"].cpu().numpy().copy(), rew.cpu().numpy().copy(), trunc.cpu().numpy().copy(), env.raw()[0].copy()))
+        for a, b in zip(*outs):
+            assert np.array_equal(a, b), step
+    assert np.array_equal(one.get_state()[0], split.get_state()[0])
+    for env in envs:
+        env.close()
+
+
 @pytest.mark.parametrize("seed", range(14))
 def test_randomised_scene_sweep(seed):
     """Wider net than the hand-picked cases above: random array size, resolution, regime and device per seed;
