@@ -430,11 +430,11 @@ static int qd_launch_ground(qd_handle* h, const int32_t* env_ids, int base, int 
         }
         if (stages & 2) {
         // A hop component lies in one total-charge sector of the kept states: at most 4 states for 2 dots (16 candidates), 12 for
-        // 3 dots; the launches of size classes that cannot occur are skipped.  Small launches (launch-bound: config 1) stay on one
-        // stream; large ones put the memory solver of the rare 13..32-state blocks (one long latency chain) and the wide register
-        // solvers on two side streams.
+        // 3 dots; the launches of size classes that cannot occur are skipped.  From 4 dots on the memory solver of the rare
+        // 13..32-state blocks (one long latency chain: 0.4 ms for 8 envs, 0.9 ms for 180) and the wide register solvers go on
+        // two side streams, whatever the batch.
         const int max_bin = h->N == 2 ? qd_gs_bin(4) : (h->N == 3 ? qd_gs_bin(12) : QD_GS_NBIN - 1);
-        const bool forked = batches >= 2048 || (max_bin >= 9 && batches < (unsigned)h->cus);   // (a single image: every launch is one wave's latency)
+        const bool forked = max_bin >= 9;            // (8-dot, 4 envs: 1 760 -> 2 520 env-steps/s, 8 envs 3 390 -> 3 590; 2 and 3 dots have no memory-solver launch to hide)
         hipStream_t s9 = forked ? h->side : s, s48 = forked ? h->side2 : s;
         if (forked) {
             QD_HIP(hipEventRecord(h->ev_fork, s));
