@@ -514,10 +514,10 @@ def test_dataset_generator_format_and_values(tmp_path):
     gen.close()
 
 
-@pytest.mark.parametrize("N,R,B", [(2, 32, 3), (4, 64, 2), (4, 128, 2), (3, 200, 1)])
+@pytest.mark.parametrize("N,R,B", [(2, 32, 3), (4, 64, 2), (3, 100, 2), (4, 128, 2), (3, 200, 1)])
 def test_percentiles_are_numpy_exact_on_both_kernel_paths(N, R, B):
     """qd_k_percentile keeps an image's keys in registers when it has at most 32 768 values and re-reads them from
-    memory otherwise (4 dots at 128x128: 49 152 values; 3 dots at 200x200: 80 000, not a multiple of the block): both
+    memory otherwise (4 dots at 128x128: 49 152 values; 3 dots at 200x200: 80 000; 3 dots at 100x100: 20 000 cached values, not a multiple of the block): both
     must reproduce numpy's linear-interpolation percentiles of the GPU's own raw signal bit for bit, after a reset and
     after random steps (ties and equal leading key bytes occur in flat images)."""
     import torch
