@@ -163,9 +163,11 @@ __global__ void qd_k_telegraph(const int* __restrict__ env_ids, int n_env, int C
 // ---------------------------------------------------------------------------
 // a5/a8/a9/a10: one pixel per lane.  grid = (ceil(P/BLOCK), C, n_env).
 // ---------------------------------------------------------------------------
-#define QD_CAND_BLOCK 128
+#ifndef QD_CAND_BLOCK
+#define QD_CAND_BLOCK 64        // one tile (wave) per block: a finished wave frees its 20 KB of LDS at once; behind the tile search most
+#endif                          // blocks have nothing to do and the flagged tiles run for ~0.5 ms (2 tiles per block: redo pass 13.6 -> 12.1 us)
 #ifndef QD_CAND_WAVES
-#define QD_CAND_WAVES 2         // <= 256 VGPRs: 2 waves per SIMD, which is also what the 40 KB of LDS per block allows
+#define QD_CAND_WAVES 2         // <= 256 VGPRs: 2 waves per SIMD, which is also what the 20 KB of LDS per wave allows
 #endif
 
 // REDO: second pass behind the tile search (only the pixels it flagged; their front end comes with the record)
